@@ -1,0 +1,146 @@
+"""ctypes binding of libptcore.so (include/ptcore.h).
+
+The library is the product; there is no Python or CPU fallback.  Importing this module fails loudly
+when the shared object has not been built (``__graft_entry__.build()`` or ``make -C csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptcore.so")
+
+PTC_MAX_BOUNCES_CAP = 64
+
+PTC_OK = 0
+PTC_ERR_INVALID = -1
+PTC_ERR_NO_DEVICE = -2
+PTC_ERR_HIP = -3
+PTC_ERR_OOM = -4
+PTC_ERR_BVH = -5
+PTC_ERR_STACK = -6
+PTC_ERR_NO_SCENE = -7
+
+METHOD_MEGAKERNEL = 0
+METHOD_STREAMING = 1
+
+DISPLAY_FINAL, DISPLAY_COLOR, DISPLAY_NORMAL, DISPLAY_DEPTH = 0, 1, 2, 3
+BUF_COLOR, BUF_NORMAL, BUF_DEPTH, BUF_FINAL = 0, 1, 2, 3
+
+
+class ptc_object(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("index", C.c_uint32), ("m", C.c_float * 16), ("inv_m", C.c_float * 16),
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
+
+
+class ptc_sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float)]
+
+
+class ptc_material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("p", C.c_float * 4)]
+
+
+class ptc_bvh_node(C.Structure):
+    _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("first_child_or_primitive", C.c_uint32), ("primitive_count", C.c_uint32)]
+
+
+class ptc_scene_desc(C.Structure):
+    _fields_ = [("objects", C.POINTER(ptc_object)), ("object_count", C.c_uint32),
+                ("object_material_indices", C.POINTER(C.c_uint32)),
+                ("spheres", C.POINTER(ptc_sphere)), ("sphere_count", C.c_uint32),
+                ("materials", C.POINTER(ptc_material)), ("material_count", C.c_uint32),
+                ("positions", C.POINTER(C.c_float)), ("vertex_count", C.c_uint32),
+                ("indices", C.POINTER(C.c_uint32)), ("index_count", C.c_uint32),
+                ("bvh", C.POINTER(ptc_bvh_node)), ("bvh_node_count", C.c_uint32)]
+
+
+class ptc_camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("rotation_wxyz", C.c_float * 4), ("vfov", C.c_float)]
+
+
+class ptc_denoiser_params(C.Structure):
+    _fields_ = [("filter_size", C.c_int32), ("color_weight", C.c_float), ("normal_weight", C.c_float),
+                ("position_weight", C.c_float)]
+
+
+class ptc_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_bounces", C.c_int32), ("method", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ptc_stats(C.Structure):
+    _fields_ = [("rays_total", C.c_uint64), ("frames", C.c_uint64), ("last_live", C.c_uint32 * PTC_MAX_BOUNCES_CAP),
+                ("bvh_node_count", C.c_uint32), ("bvh_max_depth", C.c_uint32), ("triangle_count", C.c_uint32),
+                ("stack_capacity", C.c_uint32)]
+
+
+# every symbol include/ptcore.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "ptc_abi_version": (C.c_int, []),
+    "ptc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ptc_create": (C.c_int, [C.POINTER(ptc_config), C.POINTER(_P)]),
+    "ptc_destroy": (None, [_P]),
+    "ptc_last_error": (C.c_char_p, [_P]),
+    "ptc_set_stream": (C.c_int, [_P, _P]),
+    "ptc_upload_scene": (C.c_int, [_P, C.POINTER(ptc_scene_desc)]),
+    "ptc_resize": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ptc_set_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ptc_restart": (C.c_int, [_P]),
+    "ptc_iteration": (C.c_int, [_P]),
+    "ptc_set_iteration": (C.c_int, [_P, C.c_int]),
+    "ptc_set_max_iterations": (C.c_int, [_P, C.c_int]),
+    "ptc_set_method": (C.c_int, [_P, C.c_int]),
+    "ptc_set_max_bounces": (C.c_int, [_P, C.c_int]),
+    "ptc_set_denoiser_params": (C.c_int, [_P, C.POINTER(ptc_denoiser_params)]),
+    "ptc_trace": (C.c_int, [_P, C.POINTER(ptc_camera)]),
+    "ptc_trace_begin": (C.c_int, [_P, C.POINTER(ptc_camera)]),
+    "ptc_trace_bounce": (C.c_int, [_P, C.c_int, _P]),
+    "ptc_trace_end": (C.c_int, [_P]),
+    "ptc_live_count_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "ptc_denoise": (C.c_int, [_P]),
+    "ptc_present_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "ptc_download": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "ptc_synchronize": (C.c_int, [_P]),
+    "ptc_get_stats": (C.c_int, [_P, C.POINTER(ptc_stats)]),
+    "ptc_intersect_rays": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
+    "ptc_build_bvh": (C.c_int, [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
+                                 C.POINTER(ptc_bvh_node), C.POINTER(C.c_uint32)]),
+    "ptc_make_object": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(ptc_sphere),
+                                   C.POINTER(C.c_float), C.POINTER(ptc_object)]),
+    "ptc_selftest_math": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libptcore.so (once).  Raises if it is missing: there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C cuda-path-tracer_amd/csrc` (there is no CPU/Python fallback)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+class PtcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"ptcore error {code}: {message}")
+        self.code = code
+
+
+def check(rc, ctx=None):
+    if rc < 0:
+        msg = lib().ptc_last_error(ctx)
+        raise PtcError(rc, msg.decode() if msg else "")
+    return rc

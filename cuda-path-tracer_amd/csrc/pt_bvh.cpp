@@ -1,0 +1,237 @@
+// pt_bvh.cpp -- host-side BVH builder of the render core.
+//
+// Produces exactly the node array the reference's bvh_from_mesh (accelerators/bvh.cpp:211-253) produces:
+// one triangle per leaf; split axis = largest extent of the centroid bounds; 2 leaves ordered by centroid;
+// <= 4 leaves split at the median; otherwise 12-bucket SAH (cost .125 + (n0*A0 + n1*A1)/A, first minimum,
+// partition by bucket <= split); nodes numbered breadth-first, root 0, children adjacent (left, left+1).
+// Unlike the reference (one shared_ptr node per triangle, serial), this builder works on index ranges
+// in place and builds large subtrees on worker threads; the result does not depend on the thread count
+// because every decision is a function of the SET of triangles in a range.
+// Where the reference leaves the order of equal centroids to std::nth_element, ties go to the lower
+// triangle index.
+#include "pt_host.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace pt {
+namespace {
+
+struct Box {
+  f3 lo, hi;
+};
+inline Box empty_box() { return Box{mk3(FLT_MAX, FLT_MAX, FLT_MAX), mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX)}; }
+inline Box grow(Box b, f3 p) { return Box{min3(b.lo, p), max3(b.hi, p)}; }
+inline Box merge(Box a, Box b) { return Box{min3(a.lo, b.lo), max3(a.hi, b.hi)}; }
+inline float area(const Box& b)
+{
+  const f3 d = b.hi - b.lo;
+  return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
+}
+inline int widest_axis(const Box& b)
+{
+  const f3 e = b.hi - b.lo;
+  return (e.x > e.y && e.x > e.z) ? 0 : (e.y > e.z) ? 1 : 2;
+}
+inline float comp(f3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+struct TmpNode {
+  Box box;
+  int32_t left, right;  // -1: leaf
+  uint32_t tri;
+};
+
+struct Builder {
+  const std::vector<Box>& tri_box;
+  const std::vector<f3>& tri_center;
+  std::vector<TmpNode>& nodes;     // preallocated 2T-1
+  std::atomic<uint32_t>& next;     // node allocator
+  std::atomic<int>& error;
+
+  uint32_t leaf(uint32_t t)
+  {
+    const uint32_t id = next.fetch_add(1u);
+    nodes[id] = TmpNode{tri_box[t], -1, -1, t};
+    return id;
+  }
+  uint32_t inner(uint32_t l, uint32_t r)
+  {
+    const uint32_t id = next.fetch_add(1u);
+    nodes[id] = TmpNode{merge(nodes[l].box, nodes[r].box), (int32_t)l, (int32_t)r, 0u};
+    return id;
+  }
+
+  // normalised position of a centroid inside the centroid bounds along `axis` (AABB::offset, aabb.hpp:73-80)
+  static inline float offset_along(const Box& cb, f3 c, int axis)
+  {
+    const float lo = comp(cb.lo, axis), hi = comp(cb.hi, axis);
+    float o = comp(c, axis) - lo;
+    if (hi > lo) o /= hi - lo;
+    return o;
+  }
+  static inline int bucket_of(const Box& cb, f3 c, int axis)
+  {
+    int b = (int)(12.0f * offset_along(cb, c, axis));
+    if (b == 12) b = 11;
+    return b;
+  }
+
+  // Builds the subtree over tris[0..n); returns its node id or -1.
+  int32_t build(uint32_t* tris, uint32_t n, int spawn_depth)
+  {
+    if (error.load(std::memory_order_relaxed)) return -1;
+    if (n == 0) {
+      error = PTC_ERR_BVH;
+      return -1;
+    }
+    if (n == 1) return (int32_t)leaf(tris[0]);
+
+    Box cb = empty_box();
+    for (uint32_t i = 0; i < n; ++i) cb = grow(cb, tri_center[tris[i]]);
+    const int axis = widest_axis(cb);
+
+    if (n == 2) {
+      uint32_t a = tris[0], b = tris[1];
+      if (comp(tri_center[a], axis) > comp(tri_center[b], axis)) std::swap(a, b);
+      const uint32_t l = leaf(a), r = leaf(b);
+      return (int32_t)inner(l, r);
+    }
+
+    uint32_t mid;
+    if (n <= 4) {
+      std::sort(tris, tris + n, [&](uint32_t a, uint32_t b) {
+        const float ka = comp(tri_center[a], axis), kb = comp(tri_center[b], axis);
+        return ka < kb || (ka == kb && a < b);
+      });
+      mid = n / 2;
+    } else {
+      int count[12] = {};
+      Box bounds[12];
+      for (auto& b : bounds) b = empty_box();
+      Box all = empty_box();
+      for (uint32_t i = 0; i < n; ++i) {
+        const int b = bucket_of(cb, tri_center[tris[i]], axis);
+        if (b < 0 || b > 11) {
+          error = PTC_ERR_BVH;
+          return -1;
+        }
+        ++count[b];
+        bounds[b] = merge(bounds[b], tri_box[tris[i]]);
+        all = merge(all, tri_box[tris[i]]);
+      }
+      const float all_area = area(all);
+      int best = 0;
+      float best_cost = 0.0f;
+      for (int s = 0; s < 11; ++s) {
+        Box b0 = empty_box(), b1 = empty_box();
+        int c0 = 0, c1 = 0;
+        for (int j = 0; j <= s; ++j) {
+          b0 = merge(b0, bounds[j]);
+          c0 += count[j];
+        }
+        for (int j = s + 1; j < 12; ++j) {
+          b1 = merge(b1, bounds[j]);
+          c1 += count[j];
+        }
+        const float cost = .125f + ((float)c0 * area(b0) + (float)c1 * area(b1)) / all_area;
+        if (s == 0 || cost < best_cost) {
+          best_cost = cost;
+          best = s;
+        }
+      }
+      uint32_t* split = std::partition(tris, tris + n, [&](uint32_t t) { return bucket_of(cb, tri_center[t], axis) <= best; });
+      mid = (uint32_t)(split - tris);
+      if (mid == 0 || mid == n) {  // reference: panic("Shouldn't happen!"), bvh.cpp:84-85
+        error = PTC_ERR_BVH;
+        return -1;
+      }
+    }
+
+    int32_t l = -1, r = -1;
+    if (spawn_depth > 0 && n > 32768u) {
+      std::thread worker([&] { l = build(tris, mid, spawn_depth - 1); });
+      r = build(tris + mid, n - mid, spawn_depth - 1);
+      worker.join();
+    } else {
+      l = build(tris, mid, 0);
+      r = build(tris + mid, n - mid, 0);
+    }
+    if (l < 0 || r < 0) return -1;
+    return (int32_t)inner((uint32_t)l, (uint32_t)r);
+  }
+};
+
+}  // namespace
+
+int build_bvh(const float* positions, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+              ptc_bvh_node* out, uint32_t* max_depth)
+{
+  const uint32_t T = index_count / 3u;
+  if (T == 0) return PTC_ERR_BVH;
+  for (uint32_t i = 0; i < T * 3u; ++i)
+    if (indices[i] >= vertex_count) return PTC_ERR_INVALID;
+
+  std::vector<Box> tri_box(T);
+  std::vector<f3> tri_center(T);
+  std::vector<uint32_t> tris(T);
+  for (uint32_t t = 0; t < T; ++t) {
+    Box b = empty_box();
+    for (int k = 0; k < 3; ++k) {
+      const float* p = positions + 3u * (size_t)indices[3u * t + k];
+      b = grow(b, mk3(p[0], p[1], p[2]));
+    }
+    tri_box[t] = b;
+    tri_center[t] = (b.lo + b.hi) / 2.0f;
+    tris[t] = t;
+  }
+
+  std::vector<TmpNode> nodes(2u * (size_t)T);
+  std::atomic<uint32_t> next{0u};
+  std::atomic<int> error{0};
+  Builder builder{tri_box, tri_center, nodes, next, error};
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  int spawn_depth = 0;
+  while ((1u << spawn_depth) < hw && spawn_depth < 6) ++spawn_depth;
+  const int32_t root = builder.build(tris.data(), T, spawn_depth);
+  if (root < 0) return error.load() ? error.load() : PTC_ERR_BVH;
+
+  // breadth-first numbering (bvh.cpp:228-250): node k of the queue gets linear index k
+  const uint32_t total = 2u * T - 1u;
+  std::vector<uint32_t> queue(total), depth(total);
+  uint32_t head = 0, tail = 0, deepest = 0;
+  queue[tail] = (uint32_t)root;
+  depth[tail] = 0;
+  ++tail;
+  auto emit = [&](uint32_t slot, const TmpNode& n) {
+    ptc_bvh_node& o = out[slot];
+    o.aabb_min[0] = n.box.lo.x; o.aabb_min[1] = n.box.lo.y; o.aabb_min[2] = n.box.lo.z;
+    o.aabb_max[0] = n.box.hi.x; o.aabb_max[1] = n.box.hi.y; o.aabb_max[2] = n.box.hi.z;
+    o.first_child_or_primitive = n.left < 0 ? n.tri * 3u : 0u;
+    o.primitive_count = n.left < 0 ? 1u : 0u;
+  };
+  emit(0, nodes[root]);
+  while (head < tail) {
+    const TmpNode& cur = nodes[queue[head]];
+    deepest = std::max(deepest, depth[head]);
+    if (cur.left >= 0) {
+      out[head].first_child_or_primitive = tail;
+      emit(tail, nodes[cur.left]);
+      queue[tail] = (uint32_t)cur.left;
+      depth[tail] = depth[head] + 1;
+      ++tail;
+      emit(tail, nodes[cur.right]);
+      queue[tail] = (uint32_t)cur.right;
+      depth[tail] = depth[head] + 1;
+      ++tail;
+    }
+    ++head;
+  }
+  if (max_depth) *max_depth = deepest;
+  return (int)tail;
+}
+
+}  // namespace pt

@@ -1,0 +1,118 @@
+// pt_device.hpp -- device-visible types of the render core and the launch interface between the
+// C ABI (ptcore.cpp) and the HIP kernels (pt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_math.hpp"
+
+namespace pt {
+
+constexpr int kWave = 64;            // gfx950 wavefront
+constexpr int kChunk = 64;           // paths per compaction chunk = one wavefront
+constexpr int kStackDepth = 64;      // traversal stack entries per ray (LDS, [depth][lane])
+constexpr int kMaxBounces = 64;      // == PTC_MAX_BOUNCES_CAP
+
+// error bits in DeviceCounters::flags
+constexpr uint32_t kFlagStackOverflow = 1u;
+
+// Same 160-byte layout as ptc_object / the reference's GPUObject (scene.hpp:16-22)
+struct DObject {
+  uint32_t type;
+  uint32_t index;
+  m4 m;
+  m4 inv_m;
+  float bmin[3];
+  float bmax[3];
+};
+static_assert(sizeof(DObject) == 160, "object layout");
+
+struct DMaterial {
+  int32_t type;
+  float p[4];
+};
+static_assert(sizeof(DMaterial) == 20, "material layout");
+
+// Read-only scene in HBM.
+//   bvh: two float4 per node: {min.xyz, bits(first_child_or_primitive)}, {max.xyz, bits(primitive_count)}
+struct DScene {
+  const DObject* objects;
+  const uint32_t* object_material;
+  const float4* spheres;  // center.xyz, radius
+  const DMaterial* materials;
+  const float* positions;
+  const uint32_t* indices;
+  const float4* bvh;
+  uint32_t object_count;
+  uint32_t bvh_node_count;
+};
+
+// Camera constants prepared on the host once per frame (GPUCamera, camera.hpp:10-15, plus the
+// per-frame invariants of generate_ray, ray_gen.cu:37-47, hoisted out of the per-pixel code).
+struct DCamera {
+  m4 cam;            // translate(position) * mat4_cast(rotation)
+  f3 origin;         // (cam * (0,0,0,1)).xyz
+  float vw, vh;      // viewport width / height
+  float llx, lly;    // lower-left corner x, y  ( = -(vw/2), -(vh/2) )
+  uint32_t width, height;
+};
+
+// Live-path state, one float4 per path and array (48 B/path):
+//   o4 = origin.xyz, bits(pixel | tmin_flag<<31)   tmin_flag: t_min is 1e-5 (after a dielectric) instead of 1e-4
+//   d4 = direction.xyz, unused
+//   t4 = throughput.rgb, unused
+struct DPaths {
+  float4* o4;
+  float4* d4;
+  float4* t4;
+};
+
+// Closest-hit record written by the trace kernel (32 B/path):
+//   tp = t (or -1 on miss), point.xyz ;  nm = normal.xyz, bits(material | side<<31)
+// (point is stored because for spheres the reference keeps the TRANSFORMED object-space hit point,
+//  path_tracer.cu:93, which is not origin + direction * t)
+struct DHits {
+  float4* tp;
+  float4* nm;
+};
+
+// Accumulated framebuffers (running means): color4 = rgb,-  ;  nd4 = normal.xyz, depth
+struct DFrame {
+  float4* color4;
+  float4* nd4;
+};
+
+struct DeviceCounters {
+  uint32_t live[kMaxBounces + 1];  // live paths entering bounce b of the current frame
+  uint32_t flags;
+  uint32_t pad;
+  unsigned long long rays_total;
+};
+
+struct DDenoise {
+  float c_phi, n_phi, p_phi;
+};
+
+// ---- launch interface (implemented in pt_kernels.hip) ----
+void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
+                   DPaths paths, DeviceCounters* counters);
+void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
+                  uint32_t* chunk_counts, DeviceCounters* counters);
+void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
+                 DeviceCounters* counters);
+void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
+                  uint32_t iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
+                  const uint32_t* chunk_offsets, DFrame fb, uint32_t pix_begin, DeviceCounters* counters);
+void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, uint32_t pix_begin,
+                       uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
+void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);
+void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst);
+void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_begin, uint32_t pix_count, const float4* color,
+                         const float4* nd, float4* out, int step_width, DDenoise params);
+void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
+                      DHits hits, DeviceCounters* counters);
+void launch_selftest(hipStream_t s, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,
+                     float* out_sin, float* out_cos);
+
+}  // namespace pt

@@ -1,0 +1,714 @@
+// pt_kernels.hip -- gfx950 kernels of the render core (wave64, LDS traversal stacks, ballot compaction).
+//
+// Arithmetic contract: every float operation on the path (ray generation, intersection, shading) is a
+// single IEEE binary32 operation in a fixed order (built with -ffp-contract=off and correctly rounded
+// divide/sqrt), because the reference's streaming mode seeds its RNG from the COMPACTED slot index
+// (path_tracer.cu:297-301): one hit/miss decision that differs moves every later path to another slot.
+// The parity tests therefore compare with the CPU oracle bit for bit.
+//
+// Frame pipeline (streaming mode, PathTracer::path_trace path_tracer.cu:413-471):
+//   raygen                                 generate_rays / raygen_kernel   (ray_gen.cu:11-32)
+//   per bounce b:
+//     trace   closest hit per live path    intersection_kernel             (path_tracer.cu:271-290)
+//             + per-wavefront live count (ballot/popcount)
+//     scan    exclusive scan of the per-wavefront counts -> compaction offsets, live[b+1]
+//     shade   material + sky + G-buffer    material_kernel                 (path_tracer.cu:292-315)
+//             fused with the stable compaction scatter   thrust::stable_partition (path_tracer.cu:454-457)
+//             and with the final gather of paths that end here  final_gathering_kernel (path_tracer.cu:317-330)
+// A path that ends (miss, or the bounce cap) is accumulated into the framebuffer at once; only live
+// paths are kept, in their original order, so slot indices equal the reference's.
+
+#include "pt_device.hpp"
+#include "pt_rng.hpp"
+
+#include <float.h>
+
+namespace pt {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t rank_below(uint64_t mask)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+
+struct Ray {
+  f3 o;
+  float tmin;
+  f3 d;
+  float tmax;
+};
+__device__ __forceinline__ f3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }
+
+struct Hit {
+  float t;
+  f3 p;
+  f3 n;
+  uint32_t mat;
+  uint32_t side;  // 0 front, 1 back
+};
+
+// ------------------------------------------------------------------------------------------------
+// intersection tests (reference intersections.cuh)
+// ------------------------------------------------------------------------------------------------
+// ray_aabb_intersection_test, intersections.cuh:87-103: no t-range, boxes behind the origin pass
+__device__ __forceinline__ bool ray_aabb(const f3 o, const f3 d, const f3 bmin, const f3 bmax)
+{
+  if (bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z) return false;
+  const f3 t0 = (bmin - o) / d;
+  const f3 t1 = (bmax - o) / d;
+  const f3 rmin = min3(t0, t1);
+  const f3 rmax = max3(t0, t1);
+  const float minmax = sel_min(sel_min(rmax.x, rmax.y), rmax.z);
+  const float maxmin = sel_max(sel_max(rmin.x, rmin.y), rmin.z);
+  return minmax >= maxmin;
+}
+
+// ray_sphere_intersection_test, intersections.cuh:7-41
+__device__ __forceinline__ bool ray_sphere(const Ray& ray, const f3 center, const float radius, Hit& rec)
+{
+  const f3 oc = ray.o - center;
+  const float a = dot(ray.d, ray.d);
+  const float b = 2.0f * dot(ray.d, oc);
+  const float c = dot(oc, oc) - radius * radius;
+  const float disc = b * b - 4.0f * a * c;
+  if (disc < 0.0f) return false;
+  const float sq = ieee_sqrt(disc);
+  const float t1 = (-b - sq) / (2.0f * a);
+  const float t2 = (-b + sq) / (2.0f * a);
+  float t;
+  if (t1 >= ray.tmin && t1 <= ray.tmax) t = t1;
+  else if (t2 >= ray.tmin && t2 <= ray.tmax) t = t2;
+  else return false;
+  rec.t = t;
+  rec.p = ray_at(ray, t);
+  const f3 outward = (rec.p - center) / radius;
+  rec.side = dot(ray.d, outward) < 0.0f ? 0u : 1u;
+  rec.n = rec.side == 0u ? outward : -outward;
+  return true;
+}
+
+// ray_triangle_intersection_test, intersections.cuh:49-85 (t == t_max accepted)
+__device__ __forceinline__ bool ray_triangle(const Ray& ray, const f3 p0, const f3 p1, const f3 p2, Hit& rec)
+{
+  const float EPS = 0.0000001f;
+  const f3 e1 = p1 - p0;
+  const f3 e2 = p2 - p0;
+  const f3 h = cross(ray.d, e2);
+  const float a = dot(e1, h);
+  if (a > -EPS && a < EPS) return false;
+  const float f = 1.0f / a;
+  const f3 s = ray.o - p0;
+  const float u = f * dot(s, h);
+  if (u < 0.0f || u > 1.0f) return false;
+  const f3 q = cross(s, e1);
+  const float v = f * dot(ray.d, q);
+  if (v < 0.0f || u + v > 1.0f) return false;
+  const float t = f * dot(e2, q);
+  if (t < ray.tmin || t > ray.tmax) return false;
+  rec.t = t;
+  rec.p = ray_at(ray, t);
+  const f3 outward = normalize(cross(e1, e2));
+  rec.side = dot(ray.d, outward) < 0.0f ? 0u : 1u;
+  rec.n = rec.side == 0u ? outward : -outward;
+  return true;
+}
+
+// inverse_transform_ray, transform.hpp:51-58: direction re-normalised, t range copied unscaled
+__device__ __forceinline__ void inverse_transform_ray(const m4& inv_m, const Ray& ray, f3& o, f3& d)
+{
+  o = xform_point(inv_m, ray.o);
+  d = normalize(xform_vector(inv_m, ray.d));
+}
+
+// ray_mesh_intersection_test, path_tracer.cu:36-76.  Depth-first, left child first, every inner box
+// the line crosses is entered (the reference has no t culling).  The stack lives in LDS, laid out
+// [depth][lane] so that a push or pop of the whole wavefront touches 64 consecutive banks.
+__device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObject* obj, Hit& rec, uint32_t* stack,
+                                         uint32_t& flags)
+{
+  bool hit = false;
+  f3 oo, od;
+  inverse_transform_ray(obj->inv_m, ray, oo, od);
+  if (sc.bvh_node_count == 0u) return false;
+
+  int sp = 0;
+  stack[0] = 0u;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    const uint32_t node = stack[sp * kWave];
+    const float4 n0 = sc.bvh[2u * node];
+    const float4 n1 = sc.bvh[2u * node + 1u];
+    const uint32_t first = __float_as_uint(n0.w);
+    const uint32_t count = __float_as_uint(n1.w);
+    if (count != 0u) {
+      const uint32_t i0 = sc.indices[first], i1 = sc.indices[first + 1u], i2 = sc.indices[first + 2u];
+      const f3 p0 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i0));
+      const f3 p1 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i1));
+      const f3 p2 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i2));
+      if (ray_triangle(ray, p0, p1, p2, rec)) {
+        hit = true;
+        ray.tmax = rec.t;
+      }
+    } else if (ray_aabb(oo, od, xyz(n0), xyz(n1))) {
+      if (sp + 2 > kStackDepth) {
+        flags |= kFlagStackOverflow;
+      } else {
+        stack[sp * kWave] = first + 1u;
+        stack[(sp + 1) * kWave] = first;
+        sp += 2;
+      }
+    }
+  }
+  return hit;
+}
+
+// ray_scene_intersection_test + ray_object_intersection_test, path_tracer.cu:78-128
+__device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, uint32_t* stack, uint32_t& flags)
+{
+  bool hit = false;
+  for (uint32_t i = 0; i < sc.object_count; ++i) {
+    const DObject* obj = sc.objects + i;
+    if (!ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax))) continue;
+    bool h = false;
+    if (obj->type == 0u) {
+      Ray tr;
+      inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
+      tr.tmin = ray.tmin;
+      tr.tmax = ray.tmax;
+      const float4 sp = sc.spheres[obj->index];
+      h = ray_sphere(tr, xyz(sp), sp.w, rec);
+      if (h) {
+        rec.p = xform_point(obj->m, rec.p);
+        rec.t = length(rec.p - ray.o);
+        rec.n = xform_normal(obj->inv_m, rec.n);
+      }
+    } else {
+      h = ray_mesh(ray, sc, obj, rec, stack, flags);
+    }
+    if (h) {
+      hit = true;
+      rec.mat = sc.object_material[i];
+      ray.tmax = rec.t;
+    }
+  }
+  return hit;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shading (path_tracer.cu:29-34, 130-201; distributions.cuh:6-19)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f3 background(const f3 dir)
+{
+  const f3 u = normalize(dir);
+  const float t = 0.5f * (u.y + 1.0f);
+  return mk3(0.5f, 0.7f, 1.0f) * (1.0f - t) + mk3(1.0f, 1.0f, 1.0f) * t;  // glm::lerp = x*(1-a) + y*a
+}
+
+__device__ __forceinline__ f3 random_on_unit_sphere(Minstd& rng)
+{
+  const float phi = 2.f * 3.14159265358979323846264338327950288f * rng.uniform();
+  const float cos_theta = 2.f * rng.uniform() - 1.f;
+  const float sin_theta = ieee_sqrt(1.0f - cos_theta * cos_theta);
+  float s, c;
+  det_sincos(phi, s, c);
+  return mk3(c * sin_theta, s * sin_theta, cos_theta);
+}
+
+__device__ __forceinline__ float schlick(float cosine, float ref_idx)
+{
+  float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+  r0 = r0 * r0;
+  const float x = 1.0f - cosine;
+  const float x2 = x * x;
+  const float x4 = x2 * x2;
+  return r0 + (1.0f - r0) * (x4 * x);
+}
+
+// evaluate_material, path_tracer.cu:138-201.  tmin_flag: ray.t_min is 1e-5 from now on (dielectric).
+__device__ __forceinline__ void evaluate_material(f3& ro, f3& rd, bool& tmin_flag, const f3 hp, const f3 hn,
+                                                  const uint32_t side, const DMaterial m, Minstd& rng, f3& color)
+{
+  ro = hp - hn * (1e-4f * sign_of(dot(rd, hn)));
+  if (m.type == 0) {
+    f3 dir = normalize(hn + random_on_unit_sphere(rng));
+    if (fabs((double)dir.x) < 1e-8 && fabs((double)dir.y) < 1e-8 && fabs((double)dir.z) < 1e-8) dir = hn;
+    rd = dir;
+    color = color * mk3(m.p[0], m.p[1], m.p[2]);
+  } else if (m.type == 1) {
+    const f3 reflected = rd - (hn * dot(hn, rd)) * 2.0f;
+    const f3 dir = reflected + random_on_unit_sphere(rng) * m.p[3];
+    rd = dir;
+    if (dot(dir, hn) > 0.0f) color = color * mk3(m.p[0], m.p[1], m.p[2]);
+    else color = mk3(0.0f, 0.0f, 0.0f);
+  } else {
+    const float ior = m.p[0];
+    const float ratio = side == 0u ? (1.0f / ior) : ior;
+    const f3 unit = normalize(rd);
+    const float cos_theta = sel_min(dot(-unit, hn), 1.0f);
+    const float sin_theta = ieee_sqrt(1.0f - cos_theta * cos_theta);
+    const bool cannot_refract = ratio * sin_theta > 1.0f;
+    f3 dir;
+    if (cannot_refract || schlick(cos_theta, ratio) > rng.uniform()) {
+      dir = unit - (hn * dot(hn, unit)) * 2.0f;
+    } else {
+      const float dv = dot(hn, unit);
+      const float k = 1.0f - ratio * ratio * (1.0f - dv * dv);
+      dir = (k >= 0.0f) ? (unit * ratio - hn * (ratio * dv + ieee_sqrt(k))) : mk3(0.0f, 0.0f, 0.0f);
+    }
+    ro = hp;
+    rd = dir;
+    tmin_flag = true;
+  }
+}
+
+// final_gather, path_tracer.cu:203-219
+__device__ __forceinline__ float running_mean(uint32_t iteration, float old_v, float new_v)
+{
+  const float sc = (float)(iteration + 1u);
+  return iteration == 0u ? new_v : (old_v * (sc - 1.0f) + new_v) / sc;
+}
+__device__ __forceinline__ void accumulate_color(float4* color4, uint32_t local_pixel, uint32_t iteration, f3 c)
+{
+  float4 old = iteration == 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : color4[local_pixel];
+  old.x = running_mean(iteration, old.x, c.x);
+  old.y = running_mean(iteration, old.y, c.y);
+  old.z = running_mean(iteration, old.z, c.z);
+  old.w = 0.0f;
+  color4[local_pixel] = old;
+}
+__device__ __forceinline__ void accumulate_nd(float4* nd4, uint32_t local_pixel, uint32_t iteration, f3 n, float depth)
+{
+  float4 old = iteration == 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : nd4[local_pixel];
+  old.x = running_mean(iteration, old.x, n.x);
+  old.y = running_mean(iteration, old.y, n.y);
+  old.z = running_mean(iteration, old.z, n.z);
+  old.w = running_mean(iteration, old.w, depth);
+  nd4[local_pixel] = old;
+}
+
+// generate_ray, ray_gen.cu:34-61 (frame invariants hoisted into DCamera)
+__device__ __forceinline__ void generate_ray(const DCamera& cam, float fx, float fy, f3& o, f3& d)
+{
+  const float u = fx / (float)(cam.width - 1u);
+  const float v = ((float)cam.height - fy) / (float)(cam.height - 1u);
+  const float dx = cam.llx + cam.vw * u;
+  const float dy = cam.lly + cam.vh * v;
+  o = cam.origin;
+  d = normalize(xform_vector(cam.cam, mk3(dx, dy, -1.0f)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// raygen_kernel, ray_gen.cu:11-32.  Slot s of this context holds pixel pix_begin + s.
+__global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
+                                                DPaths paths, DeviceCounters* counters)
+{
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s == 0u) {
+    counters->live[0] = pix_count;
+  }
+  if (s >= pix_count) return;
+  const uint32_t pixel = pix_begin + s;
+  const uint32_t x = pixel % cam.width, y = pixel / cam.width;
+  Minstd rng;
+  rng.seed(path_seed(pixel, iteration));
+  const float fx = (float)x + rng.uniform();
+  const float fy = (float)y + rng.uniform();
+  f3 o, d;
+  generate_ray(cam, fx, fy, o, d);
+  paths.o4[s] = make_float4(o.x, o.y, o.z, __uint_as_float(pixel));
+  paths.d4[s] = make_float4(d.x, d.y, d.z, 0.0f);
+  paths.t4[s] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+}
+
+__device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
+{
+  const float4 o = paths.o4[s];
+  const float4 d = paths.d4[s];
+  Ray r;
+  r.o = xyz(o);
+  r.d = xyz(d);
+  r.tmin = (__float_as_uint(o.w) >> 31) ? 1e-5f : 1e-4f;
+  r.tmax = FLT_MAX;
+  return r;
+}
+
+// intersection_kernel, path_tracer.cu:271-290.  One wavefront per 64-path chunk; also produces the
+// chunk's live count for the compaction scan.
+__global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits hits, int bounce, uint32_t* chunk_counts,
+                                                 DeviceCounters* counters)
+{
+  __shared__ uint32_t s_stack[kStackDepth * kWave];
+  const uint32_t n = counters->live[bounce];
+  const uint32_t s = blockIdx.x * kWave + threadIdx.x;
+  if (blockIdx.x * kWave >= n) return;
+  bool hit = false;
+  uint32_t flags = 0u;
+  if (s < n) {
+    const Ray ray = load_ray(paths, s);
+    Hit rec;
+    rec.t = 0.0f;
+    rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+    rec.mat = 0u;
+    rec.side = 0u;
+    hit = ray_scene(ray, sc, rec, s_stack + threadIdx.x, flags);
+    hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
+    hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+    if (flags) atomicOr(&counters->flags, flags);
+  }
+  const uint64_t live = __ballot(hit);
+  if (threadIdx.x == 0u) chunk_counts[blockIdx.x] = (uint32_t)__popcll(live);
+}
+
+// Exclusive scan of the per-chunk live counts (one workgroup; <= ~32k chunks at 1080p).
+// Writes live[bounce+1] (0 after the last bounce: nothing survives the cap) and the ray counter.
+__global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, const uint32_t* chunk_counts,
+                                               uint32_t* chunk_offsets, DeviceCounters* counters)
+{
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  const uint32_t n = counters->live[bounce];
+  const uint32_t chunks = (n + kChunk - 1u) / kChunk;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0u) s_carry = 0u;
+  __syncthreads();
+  for (uint32_t base = 0; base < chunks; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < chunks ? chunk_counts[i] : 0u;
+    // inclusive scan inside the wavefront
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= (uint32_t)off) x += y;
+    }
+    if (lane == 63u) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t wave_prefix = 0u;
+    for (uint32_t w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+    const uint32_t carry = s_carry;
+    if (i < chunks) chunk_offsets[i] = carry + wave_prefix + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023u) s_carry = carry + wave_prefix + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0u) {
+    counters->live[bounce + 1] = last_bounce ? 0u : s_carry;
+    counters->rays_total += n;
+  }
+}
+
+// material_kernel (path_tracer.cu:292-315) + the stable compaction scatter + the final gather of
+// every path that ends at this bounce.
+__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, uint32_t iteration, int bounce,
+                                               int last_bounce, const uint32_t* slot_base, const uint32_t* chunk_offsets,
+                                               DFrame fb, uint32_t pix_begin, DeviceCounters* counters)
+{
+  const uint32_t n = counters->live[bounce];
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x * 256u >= n) return;
+  const bool active = s < n;
+  bool survives = false;
+  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), color = mk3(0, 0, 0);
+  uint32_t pixbits = 0u;
+  if (active) {
+    const float4 o4 = in.o4[s];
+    const float4 d4 = in.d4[s];
+    const float4 t4 = in.t4[s];
+    const float4 tp = hits.tp[s];
+    ro = xyz(o4);
+    rd = xyz(d4);
+    color = xyz(t4);
+    pixbits = __float_as_uint(o4.w);
+    const uint32_t pixel = pixbits & 0x7fffffffu;
+    const uint32_t local_pixel = pixel - pix_begin;
+    bool tmin_flag = (pixbits >> 31) != 0u;
+
+    if (tp.x < 0.0f) {
+      // miss: throughput *= sky; the path ends (path_tracer.cu:304-307, 283-289)
+      color = color * background(rd);
+      if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, iteration, -rd, 1e6f);  // raygen defaults, ray_gen.cu:26-28
+      accumulate_color(fb.color4, local_pixel, iteration, color);
+    } else {
+      const float4 nm = hits.nm[s];
+      const f3 hn = xyz(nm);
+      if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, iteration, hn, tp.x);  // path_tracer.cu:308-311
+      const uint32_t ms = __float_as_uint(nm.w);
+      const DMaterial m = sc.materials[ms & 0x7fffffffu];
+      // RNG re-seeded from the global slot index, then discard(bounce) (path_tracer.cu:300-301)
+      const uint32_t slot = (slot_base ? *slot_base : 0u) + s;
+      Minstd rng;
+      rng.seed(path_seed(slot, iteration));
+      rng.discard((uint32_t)bounce);
+      const f3 hp = mk3(tp.y, tp.z, tp.w);
+      evaluate_material(ro, rd, tmin_flag, hp, hn, ms >> 31, m, rng, color);
+      if (last_bounce) {
+        accumulate_color(fb.color4, local_pixel, iteration, color);  // capped paths deposit raw throughput
+      } else {
+        survives = true;
+        pixbits = pixel | (tmin_flag ? 0x80000000u : 0u);
+      }
+    }
+  }
+  const uint64_t live = __ballot(survives);
+  if (survives) {
+    const uint32_t dst = chunk_offsets[s / kChunk] + rank_below(live);
+    out.o4[dst] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixbits));
+    out.d4[dst] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+    out.t4[dst] = make_float4(color.x, color.y, color.z, 0.0f);
+  }
+}
+
+
+// path_tracing_mega_kernel, path_tracer.cu:227-269: the whole path in one thread, one RNG stream per
+// pixel (a different image from streaming mode at the same seed -- a property of the reference).
+__global__ __launch_bounds__(kWave) void k_megakernel(DScene sc, DCamera cam, uint32_t iteration, uint32_t pix_begin,
+                                                      uint32_t pix_count, int max_bounces, DFrame fb,
+                                                      DeviceCounters* counters)
+{
+  __shared__ uint32_t s_stack[kStackDepth * kWave];
+  const uint32_t s = blockIdx.x * kWave + threadIdx.x;
+  uint32_t rays = 0u, flags = 0u;
+  if (s < pix_count) {
+    const uint32_t pixel = pix_begin + s;
+    const uint32_t x = pixel % cam.width, y = pixel / cam.width;
+    Minstd rng;
+    rng.seed(path_seed(pixel, iteration));
+    const float fx = (float)x + rng.uniform();
+    const float fy = (float)y + rng.uniform();
+    Ray ray;
+    generate_ray(cam, fx, fy, ray.o, ray.d);
+    ray.tmin = 1e-4f;
+    ray.tmax = FLT_MAX;
+    f3 color = mk3(1.0f, 1.0f, 1.0f);
+    f3 normal = -ray.d;
+    float depth = 1e6f;
+    for (int i = 0; i < max_bounces; ++i) {
+      Hit rec;
+      rec.t = 0.0f;
+      rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+      rec.mat = 0u;
+      rec.side = 0u;
+      ++rays;
+      if (!ray_scene(ray, sc, rec, s_stack + threadIdx.x, flags)) {
+        color = color * background(ray.d);
+        break;
+      }
+      if (i == 0) {
+        normal = rec.n;
+        depth = rec.t;
+      }
+      bool tmin_flag = ray.tmin != 1e-4f;
+      evaluate_material(ray.o, ray.d, tmin_flag, rec.p, rec.n, rec.side, sc.materials[rec.mat], rng, color);
+      ray.tmin = tmin_flag ? 1e-5f : 1e-4f;
+    }
+    accumulate_color(fb.color4, s, iteration, color);
+    accumulate_nd(fb.nd4, s, iteration, normal, depth);
+    if (flags) atomicOr(&counters->flags, flags);
+  }
+  // one ray-counter atomic per wavefront
+  uint32_t sum = rays;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (threadIdx.x == 0u && sum) atomicAdd(&counters->rays_total, (unsigned long long)sum);
+}
+
+// intersection_kernel on caller-supplied rays (parity tests): rays_o = origin.xyz,t_min ; rays_d = direction.xyz,t_max
+__global__ __launch_bounds__(kWave) void k_intersect(DScene sc, const float4* rays_o, const float4* rays_d, uint32_t n,
+                                                     DHits hits, DeviceCounters* counters)
+{
+  __shared__ uint32_t s_stack[kStackDepth * kWave];
+  const uint32_t s = blockIdx.x * kWave + threadIdx.x;
+  if (s >= n) return;
+  const float4 o = rays_o[s], d = rays_d[s];
+  Ray ray;
+  ray.o = xyz(o);
+  ray.tmin = o.w;
+  ray.d = xyz(d);
+  ray.tmax = d.w;
+  Hit rec;
+  rec.t = 0.0f;
+  rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+  rec.mat = 0u;
+  rec.side = 0u;
+  uint32_t flags = 0u;
+  const bool hit = ray_scene(ray, sc, rec, s_stack + threadIdx.x, flags);
+  hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
+  hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+  if (flags) atomicOr(&counters->flags, flags);
+}
+
+// preview_kernel / preview_depth_kernel, path_tracer.cu:334-385.
+// mode 0: rgb of buf ; 1: normal view (xyz*0.5+0.5) ; 2: depth view (1/w, alpha 1)
+__global__ __launch_bounds__(256) void k_preview(const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= pix_count) return;
+  const float4 v = buf[i];
+  f3 c = xyz(v);
+  uint32_t alpha = 255u;
+  if (mode == 2) {
+    const float d = 1.0f / v.w;
+    c = mk3(d, d, d);
+    alpha = 1u;
+  } else if (mode == 1) {
+    c = c * 0.5f + mk3(0.5f, 0.5f, 0.5f);
+  }
+  const float g = 1.f / 2.2f;
+  c = mk3(powf(c.x, g), powf(c.y, g), powf(c.z, g));
+  auto to255 = [](float x) -> uint32_t { return (uint32_t)(unsigned char)(sel_min(sel_max(x, 0.f), 1.f) * 255.99f); };
+  rgba[i] = to255(c.x) | (to255(c.y) << 8) | (to255(c.z) << 16) | (alpha << 24);
+}
+
+// float4 framebuffer -> packed vec3 (which 0) or the w channel (which 1)
+__global__ __launch_bounds__(256) void k_pack(const float4* buf, uint32_t pix_count, int which, float* dst)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= pix_count) return;
+  const float4 v = buf[i];
+  if (which == 0) {
+    dst[3u * (size_t)i] = v.x;
+    dst[3u * (size_t)i + 1u] = v.y;
+    dst[3u * (size_t)i + 2u] = v.z;
+  } else {
+    dst[i] = v.w;
+  }
+}
+
+// denoising_kernel, denoising/edge_avoiding_a_trous_denoiser.cu:24-86.
+// The reference clamps taps to [0,W] x [0,H] INCLUSIVE (cu:39-42), so column W aliases the next row's
+// column 0 and row H is out of bounds; an index beyond the array reads element W*H-1 here.
+__global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count, const float4* color, const float4* nd,
+                                                 float4* out, int step_width, DDenoise prm)
+{
+  const uint32_t index = blockIdx.x * 256u + threadIdx.x;
+  if (index >= pix_count) return;
+  const uint32_t W = cam.width, H = cam.height;
+  const int x = (int)(index % W), y = (int)(index / W);
+  const float kernel[3] = {3.f / 8.f, 1.f / 4.f, 1.f / 16.f};
+  const f3 cval = xyz(color[index]);
+  const float4 ndc = nd[index];
+  const f3 nval = xyz(ndc);
+  f3 ro, rd;
+  generate_ray(cam, (float)x + 0.5f, (float)y + 0.5f, ro, rd);
+  const f3 pval = ro + rd * ndc.w;
+  f3 sum = mk3(0.f, 0.f, 0.f);
+  float cum_w = 0.0f;
+  const float step2 = (float)(step_width * step_width);
+  for (int dy = -2; dy <= 2; ++dy) {
+    for (int dx = -2; dx <= 2; ++dx) {
+      int u = x + dx * step_width;
+      u = u < 0 ? 0 : (u > (int)W ? (int)W : u);
+      int v = y + dy * step_width;
+      v = v < 0 ? 0 : (v > (int)H ? (int)H : v);
+      uint32_t ti = (uint32_t)u + (uint32_t)v * W;
+      if (ti >= pix_count) ti = pix_count - 1u;
+      const f3 ctemp = xyz(color[ti]);
+      f3 t = cval - ctemp;
+      float dist2 = dot(t, t);
+      const float c_w = sel_min(expf(-dist2 / prm.c_phi), 1.0f);
+      const float4 ndt = nd[ti];
+      t = nval - xyz(ndt);
+      dist2 = sel_max(dot(t, t) / step2, 0.0f);
+      const float n_w = sel_min(expf(-dist2 / prm.n_phi), 1.0f);
+      f3 to, td;
+      generate_ray(cam, (float)u + 0.5f, (float)v + 0.5f, to, td);
+      const f3 ptmp = to + td * ndt.w;
+      t = pval - ptmp;
+      dist2 = dot(t, t);
+      const float p_w = sel_min(expf(-dist2 / prm.p_phi), 1.0f);
+      const float weight = c_w * n_w * p_w;
+      const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+      const float k = kernel[adx < ady ? adx : ady];
+      sum = sum + (ctemp * weight) * k;
+      cum_w += weight * k;
+    }
+  }
+  const f3 o = sum / cum_w;
+  out[index] = make_float4(o.x, o.y, o.z, 0.0f);
+}
+
+__global__ void k_selftest(const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt, float* out_sin,
+                           float* out_cos)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out_div[i] = a[i] / b[i];
+  out_sqrt[i] = ieee_sqrt(a[i]);
+  float s, c;
+  det_sincos(a[i], s, c);
+  out_sin[i] = s;
+  out_cos[i] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+
+void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
+                   DPaths paths, DeviceCounters* counters)
+{
+  hipLaunchKernelGGL(k_raygen, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, iteration, pix_begin, pix_count,
+                     paths, counters);
+}
+void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
+                  uint32_t* chunk_counts, DeviceCounters* counters)
+{
+  hipLaunchKernelGGL(k_trace, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
+                     chunk_counts, counters);
+}
+void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
+                 DeviceCounters* counters)
+{
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, bounce, last_bounce ? 1 : 0, chunk_counts, chunk_offsets,
+                     counters);
+}
+void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
+                  uint32_t iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
+                  const uint32_t* chunk_offsets, DFrame fb, uint32_t pix_begin, DeviceCounters* counters)
+{
+  hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u)), dim3(256), 0, s, scene, in, out, hits, iteration, bounce,
+                     last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, pix_begin, counters);
+}
+void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, uint32_t pix_begin,
+                       uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters)
+{
+  hipLaunchKernelGGL(k_megakernel, dim3(div_up(pix_count, kWave)), dim3(kWave), 0, s, scene, cam, iteration, pix_begin,
+                     pix_count, max_bounces, fb, counters);
+}
+void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba)
+{
+  hipLaunchKernelGGL(k_preview, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, buf, pix_count, mode, rgba);
+}
+void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst)
+{
+  hipLaunchKernelGGL(k_pack, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, buf, pix_count, which, dst);
+}
+void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_begin, uint32_t pix_count, const float4* color,
+                         const float4* nd, float4* out, int step_width, DDenoise params)
+{
+  (void)pix_begin;
+  hipLaunchKernelGGL(k_denoise, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, pix_count, color, nd, out,
+                     step_width, params);
+}
+void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
+                      DHits hits, DeviceCounters* counters)
+{
+  hipLaunchKernelGGL(k_intersect, dim3(div_up(n, kWave)), dim3(kWave), 0, s, scene, rays_o, rays_d, n, hits, counters);
+}
+void launch_selftest(hipStream_t s, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,
+                     float* out_sin, float* out_cos)
+{
+  hipLaunchKernelGGL(k_selftest, dim3(div_up(n, 256u)), dim3(256), 0, s, a, b, n, out_div, out_sqrt, out_sin, out_cos);
+}
+
+}  // namespace pt

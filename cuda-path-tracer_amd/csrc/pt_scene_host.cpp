@@ -1,0 +1,143 @@
+// pt_scene_host.cpp -- host-side scene flattening helpers (no GPU).
+#include "pt_host.hpp"
+
+#include <cfloat>
+#include <cstring>
+
+namespace pt {
+
+// glm::inverse(mat4): cofactor expansion with glm's grouping (2x2 sub-determinants shared between
+// cofactors, determinant from the first row, one reciprocal).
+m4 inverse(const m4& a)
+{
+  const auto& m = a.c;
+  const float s00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+  const float s02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+  const float s03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+  const float s04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+  const float s06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+  const float s07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+  const float s08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+  const float s10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+  const float s11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+  const float s12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+  const float s14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+  const float s15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+  const float s16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+  const float s18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+  const float s19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+  const float s20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+  const float s22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+  const float s23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+
+  const float f0[4] = {s00, s00, s02, s03}, f1[4] = {s04, s04, s06, s07}, f2[4] = {s08, s08, s10, s11};
+  const float f3_[4] = {s12, s12, s14, s15}, f4_[4] = {s16, s16, s18, s19}, f5[4] = {s20, s20, s22, s23};
+  const float v0[4] = {m[1][0], m[0][0], m[0][0], m[0][0]};
+  const float v1[4] = {m[1][1], m[0][1], m[0][1], m[0][1]};
+  const float v2[4] = {m[1][2], m[0][2], m[0][2], m[0][2]};
+  const float v3[4] = {m[1][3], m[0][3], m[0][3], m[0][3]};
+
+  m4 adj;
+  for (int i = 0; i < 4; ++i) {
+    const float sa = (i & 1) ? -1.0f : 1.0f;  // + - + -
+    const float sb = -sa;                      // - + - +
+    adj.c[0][i] = ((v1[i] * f0[i] - v2[i] * f1[i]) + v3[i] * f2[i]) * sa;
+    adj.c[1][i] = ((v0[i] * f0[i] - v2[i] * f3_[i]) + v3[i] * f4_[i]) * sb;
+    adj.c[2][i] = ((v0[i] * f1[i] - v1[i] * f3_[i]) + v3[i] * f5[i]) * sa;
+    adj.c[3][i] = ((v0[i] * f2[i] - v1[i] * f4_[i]) + v2[i] * f5[i]) * sb;
+  }
+  const float det = (m[0][0] * adj.c[0][0] + m[0][1] * adj.c[1][0]) + (m[0][2] * adj.c[2][0] + m[0][3] * adj.c[3][0]);
+  const float inv_det = 1.0f / det;
+  m4 r;
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) r.c[j][i] = adj.c[j][i] * inv_det;
+  return r;
+}
+
+static m4 identity()
+{
+  m4 r;
+  std::memset(&r, 0, sizeof r);
+  r.c[0][0] = r.c[1][1] = r.c[2][2] = r.c[3][3] = 1.0f;
+  return r;
+}
+
+// glm mat4 * mat4: column j = ((A0*b0 + A1*b1) + A2*b2) + A3*b3
+static m4 matmul(const m4& a, const m4& b)
+{
+  m4 r;
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
+      r.c[j][i] = ((a.c[0][i] * b.c[j][0] + a.c[1][i] * b.c[j][1]) + a.c[2][i] * b.c[j][2]) + a.c[3][i] * b.c[j][3];
+  return r;
+}
+
+m4 camera_matrix(const float position[3], const float q[4])
+{
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  m4 rot = identity();  // glm::mat4_cast
+  rot.c[0][0] = 1.0f - 2.0f * (yy + zz);
+  rot.c[0][1] = 2.0f * (xy + wz);
+  rot.c[0][2] = 2.0f * (xz - wy);
+  rot.c[1][0] = 2.0f * (xy - wz);
+  rot.c[1][1] = 1.0f - 2.0f * (xx + zz);
+  rot.c[1][2] = 2.0f * (yz + wx);
+  rot.c[2][0] = 2.0f * (xz + wy);
+  rot.c[2][1] = 2.0f * (yz - wx);
+  rot.c[2][2] = 1.0f - 2.0f * (xx + yy);
+  m4 tr = identity();  // glm::translate(identity, position)
+  for (int i = 0; i < 4; ++i)
+    tr.c[3][i] = ((tr.c[0][i] * position[0] + tr.c[1][i] * position[1]) + tr.c[2][i] * position[2]) + tr.c[3][i];
+  return matmul(tr, rot);
+}
+
+int make_object(uint32_t type, uint32_t index, const float* m16, const ptc_sphere* sphere, const float* mesh_aabb6,
+                ptc_object* out)
+{
+  if (!m16 || !out || type > 1u) return PTC_ERR_INVALID;
+  if (type == 0u && !sphere) return PTC_ERR_INVALID;
+  if (type == 1u && !mesh_aabb6) return PTC_ERR_INVALID;
+  m4 m;
+  std::memcpy(&m, m16, sizeof m);
+  const m4 inv = inverse(m);
+  std::memset(out, 0, sizeof *out);
+  out->type = type;
+  out->index = type == 0u ? index : 0u;
+  std::memcpy(out->m, &m, sizeof m);
+  std::memcpy(out->inv_m, &inv, sizeof inv);
+  f3 lo, hi;
+  if (type == 0u) {
+    const f3 c = xform_point(m, mk3(sphere->center[0], sphere->center[1], sphere->center[2]));
+    const float r = length(xform_vector(m, mk3(1.0f, 0.0f, 0.0f))) * sphere->radius;
+    lo = c - mk3(r, r, r);
+    hi = c + mk3(r, r, r);
+  } else {
+    const f3 bl = mk3(mesh_aabb6[0], mesh_aabb6[1], mesh_aabb6[2]);
+    const f3 bh = mk3(mesh_aabb6[3], mesh_aabb6[4], mesh_aabb6[5]);
+    if (bl.x > bh.x || bl.y > bh.y || bl.z > bh.z) {  // transform_aabb keeps an empty box (transform.hpp:72)
+      lo = bl;
+      hi = bh;
+    } else {
+      // transform_aabb, transform.hpp:69-88: corners in the order x-major, then y, then z
+      bool first = true;
+      for (int ix = 0; ix < 2; ++ix)
+        for (int iy = 0; iy < 2; ++iy)
+          for (int iz = 0; iz < 2; ++iz) {
+            const f3 p = xform_point(m, mk3(ix ? bh.x : bl.x, iy ? bh.y : bl.y, iz ? bh.z : bl.z));
+            if (first) {
+              lo = hi = p;
+              first = false;
+            } else {
+              lo = min3(lo, p);
+              hi = max3(hi, p);
+            }
+          }
+    }
+  }
+  out->aabb_min[0] = lo.x; out->aabb_min[1] = lo.y; out->aabb_min[2] = lo.z;
+  out->aabb_max[0] = hi.x; out->aabb_max[1] = hi.y; out->aabb_max[2] = hi.z;
+  return PTC_OK;
+}
+
+}  // namespace pt

@@ -1,0 +1,705 @@
+// ptcore.cpp -- the C ABI of libptcore.so (include/ptcore.h): context, buffers, frame loop.
+//
+// One ptc_ctx owns what the reference's PathTracer owns (path_tracer.hpp:68-84): the device scene, the
+// path state, the hit records, the accumulated framebuffers, the two denoise ping-pong buffers and the
+// iteration counter.  Differences that matter for speed, not results:
+//   - no per-bounce host synchronisation: live-path counts stay in a device counter block and the
+//     kernels of bounce b read live[b] themselves (the reference reads the Thrust partition result
+//     back every bounce, path_tracer.cu:457);
+//   - path state is ping-ponged between two buffers by the fused shade+compaction kernel instead of
+//     being partitioned in place through a Thrust temporary.
+#include "../../include/ptcore.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pt_device.hpp"
+#include "pt_host.hpp"
+
+using namespace pt;
+
+static_assert(sizeof(ptc_object) == sizeof(DObject), "ptc_object must match the device object");
+static_assert(sizeof(ptc_material) == sizeof(DMaterial), "ptc_material must match the device material");
+static_assert(sizeof(ptc_bvh_node) == 32, "BVH node is 32 bytes (bvh.hpp:30)");
+static_assert(PTC_MAX_BOUNCES_CAP == kMaxBounces, "bounce cap mismatch");
+
+static thread_local std::string g_create_error;
+
+struct ptc_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // scene
+  std::vector<void*> scene_allocs;
+  DScene scene{};
+  bool has_scene = false;
+  uint32_t bvh_nodes = 0, bvh_depth = 0, triangles = 0;
+
+  // frame
+  uint32_t width = 0, height = 0;
+  uint32_t pix_begin = 0, pix_count = 0, pix_capacity = 0;
+  std::vector<void*> frame_allocs;
+  DPaths paths[2]{};
+  int cur = 0;
+  DHits hits{};
+  uint32_t* chunk_counts = nullptr;
+  uint32_t* chunk_offsets = nullptr;
+  DFrame fb{};
+  float4* den_a = nullptr;
+  float4* den_b = nullptr;
+  const float4* result = nullptr;
+  float* pack_buf = nullptr;     // 3 floats / pixel staging for downloads
+  uint32_t* rgba_buf = nullptr;  // staging for host presents
+  DeviceCounters* counters = nullptr;
+
+  int iteration = 0;
+  int max_iterations = 1;
+  int method = PTC_METHOD_STREAMING;
+  int max_bounces = 50;
+  ptc_denoiser_params den{10, 0.45f, 0.30f, 0.25f};
+  DCamera cam{};
+  bool have_cam = false;
+  bool in_frame = false;
+  uint64_t frames = 0;
+};
+
+namespace {
+
+int fail(ptc_ctx* ctx, int code, const std::string& msg)
+{
+  if (ctx) ctx->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? PTC_ERR_OOM : PTC_ERR_HIP,                   \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+int check_last(ptc_ctx* ctx, const char* what)
+{
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, PTC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  return PTC_OK;
+}
+
+int bind_device(ptc_ctx* ctx)
+{
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return PTC_OK;
+}
+
+template <typename T>
+int dev_alloc(ptc_ctx* ctx, std::vector<void*>& pool, T** out, size_t count)
+{
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+  HIP_TRY(ctx, hipMalloc(&p, bytes));
+  pool.push_back(p);
+  *out = static_cast<T*>(p);
+  return PTC_OK;
+}
+
+void free_pool(std::vector<void*>& pool)
+{
+  for (void* p : pool) (void)hipFree(p);
+  pool.clear();
+}
+
+template <typename T>
+int upload(ptc_ctx* ctx, std::vector<void*>& pool, const T** out, const T* host, size_t count)
+{
+  T* d = nullptr;
+  int rc = dev_alloc(ctx, pool, &d, count);
+  if (rc) return rc;
+  if (count) HIP_TRY(ctx, hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *out = d;
+  return PTC_OK;
+}
+
+// Camera::to_gpu_camera (camera.cpp:5-13) + the frame-invariant part of generate_ray (ray_gen.cu:37-47)
+DCamera make_camera(const ptc_camera& c, uint32_t w, uint32_t h)
+{
+  DCamera d;
+  d.cam = camera_matrix(c.position, c.rotation_wxyz);
+  const f4 o = mul(d.cam, 0.0f, 0.0f, 0.0f, 1.0f);
+  d.origin = mk3(o.x, o.y, o.z);
+  const float aspect = (float)w / (float)h;
+  d.vh = 2.0f * tanf(c.vfov / 2);
+  d.vw = aspect * d.vh;
+  // lower_left_corner = origin - horizontal/2 - vertical/2 - (0,0,focal)
+  d.llx = ((0.0f - d.vw / 2.f) - 0.0f / 2.f) - 0.0f;
+  d.lly = ((0.0f - 0.0f / 2.f) - d.vh / 2.f) - 0.0f;
+  d.width = w;
+  d.height = h;
+  return d;
+}
+
+int validate_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
+{
+  if (s->object_count && (!s->objects || !s->object_material_indices)) return fail(ctx, PTC_ERR_INVALID, "objects missing");
+  if (s->sphere_count && !s->spheres) return fail(ctx, PTC_ERR_INVALID, "spheres missing");
+  if (s->material_count && !s->materials) return fail(ctx, PTC_ERR_INVALID, "materials missing");
+  if (s->index_count % 3u) return fail(ctx, PTC_ERR_INVALID, "index_count is not a multiple of 3");
+  if (s->index_count && (!s->indices || !s->positions)) return fail(ctx, PTC_ERR_INVALID, "mesh arrays missing");
+  for (uint32_t i = 0; i < s->index_count; ++i)
+    if (s->indices[i] >= s->vertex_count) return fail(ctx, PTC_ERR_INVALID, "vertex index out of range");
+  for (uint32_t i = 0; i < s->object_count; ++i) {
+    const ptc_object& o = s->objects[i];
+    if (o.type > 1u) return fail(ctx, PTC_ERR_INVALID, "unknown object type");
+    if (o.type == 0u && o.index >= s->sphere_count) return fail(ctx, PTC_ERR_INVALID, "sphere index out of range");
+    if (s->object_material_indices[i] >= s->material_count) return fail(ctx, PTC_ERR_INVALID, "material index out of range");
+  }
+  for (uint32_t i = 0; i < s->material_count; ++i)
+    if (s->materials[i].type < 0 || s->materials[i].type > 2) return fail(ctx, PTC_ERR_INVALID, "unknown material type");
+  return PTC_OK;
+}
+
+int validate_bvh(ptc_ctx* ctx, const ptc_bvh_node* nodes, uint32_t count, uint32_t index_count)
+{
+  for (uint32_t i = 0; i < count; ++i) {
+    const ptc_bvh_node& n = nodes[i];
+    if (n.primitive_count != 0u) {
+      if ((uint64_t)n.first_child_or_primitive + 2u >= index_count) return fail(ctx, PTC_ERR_INVALID, "BVH leaf out of range");
+    } else if ((uint64_t)n.first_child_or_primitive + 1u >= count || n.first_child_or_primitive <= i) {
+      return fail(ctx, PTC_ERR_INVALID, "BVH child out of range");
+    }
+  }
+  return PTC_OK;
+}
+
+// depth of a breadth-first numbered tree (children after parents)
+uint32_t bvh_depth_of(const ptc_bvh_node* nodes, uint32_t count)
+{
+  std::vector<uint32_t> depth(count, 0u);
+  uint32_t deepest = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    deepest = std::max(deepest, depth[i]);
+    if (nodes[i].primitive_count == 0u) {
+      depth[nodes[i].first_child_or_primitive] = depth[i] + 1;
+      depth[nodes[i].first_child_or_primitive + 1] = depth[i] + 1;
+    }
+  }
+  return deepest;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptc_abi_version(void) { return PTC_ABI_VERSION; }
+
+int ptc_device_count(int* count)
+{
+  if (!count) return PTC_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    (void)hipGetLastError();
+    return fail(nullptr, PTC_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return PTC_OK;
+}
+
+const char* ptc_last_error(const ptc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ptc_create(const ptc_config* config, ptc_ctx** out)
+{
+  if (!out) return fail(nullptr, PTC_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(nullptr, PTC_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  }
+  const int device = config ? config->device : 0;
+  if (device < 0 || device >= n) return fail(nullptr, PTC_ERR_NO_DEVICE, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, PTC_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, PTC_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+
+  ptc_ctx* ctx = new (std::nothrow) ptc_ctx();
+  if (!ctx) return fail(nullptr, PTC_ERR_OOM, "out of host memory");
+  ctx->device = device;
+  if (config) {
+    if (config->max_bounces > 0) ctx->max_bounces = std::min(config->max_bounces, (int)kMaxBounces);
+    if (config->method == PTC_METHOD_MEGAKERNEL) ctx->method = PTC_METHOD_MEGAKERNEL;
+  }
+  auto bail = [&](int rc) {
+    g_create_error = ctx->err;
+    ptc_destroy(ctx);
+    return rc;
+  };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(ctx, PTC_ERR_HIP, "hipSetDevice failed"));
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(ctx, PTC_ERR_HIP, "hipStreamCreate failed"));
+  ctx->stream = ctx->own_stream;
+  void* p = nullptr;
+  if (hipMalloc(&p, sizeof(DeviceCounters)) != hipSuccess) return bail(fail(ctx, PTC_ERR_OOM, "hipMalloc(counters) failed"));
+  ctx->counters = static_cast<DeviceCounters*>(p);
+  if (hipMemset(ctx->counters, 0, sizeof(DeviceCounters)) != hipSuccess) return bail(fail(ctx, PTC_ERR_HIP, "hipMemset failed"));
+  *out = ctx;
+  return PTC_OK;
+}
+
+void ptc_destroy(ptc_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  free_pool(ctx->scene_allocs);
+  free_pool(ctx->frame_allocs);
+  if (ctx->counters) (void)hipFree(ctx->counters);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int ptc_set_stream(ptc_ctx* ctx, void* hip_stream)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return PTC_OK;
+}
+
+int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
+{
+  if (!ctx || !s) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  if (int rc = validate_scene(ctx, s)) return rc;
+
+  // bottom-level BVH (scene_description.cpp:99-101), unless the caller brought one
+  std::vector<ptc_bvh_node> built;
+  const ptc_bvh_node* nodes = s->bvh;
+  uint32_t node_count = s->bvh ? s->bvh_node_count : 0u;
+  uint32_t depth = 0;
+  if (s->index_count == 0u) {
+    nodes = nullptr;
+    node_count = 0u;  // the reference panics on an empty mesh (bvh.cpp:200); here it is a scene without mesh
+  } else if (!nodes) {
+    built.resize((size_t)s->index_count / 3u * 2u);
+    const int rc = build_bvh(s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth);
+    if (rc < 0) return fail(ctx, rc, "BVH build failed (empty SAH side: coincident centroids?)");
+    node_count = (uint32_t)rc;
+    nodes = built.data();
+  } else {
+    if (int rc = validate_bvh(ctx, nodes, node_count, s->index_count)) return rc;
+    depth = bvh_depth_of(nodes, node_count);
+  }
+  // depth-first traversal pushes two children per inner node popped: stack need = depth + 1
+  if (node_count && depth + 2u > (uint32_t)kStackDepth)
+    return fail(ctx, PTC_ERR_STACK, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack");
+
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_pool(ctx->scene_allocs);
+  ctx->has_scene = false;
+  DScene d{};
+  const DObject* objects = nullptr;
+  if (int rc = upload(ctx, ctx->scene_allocs, &objects, reinterpret_cast<const DObject*>(s->objects), s->object_count)) return rc;
+  d.objects = objects;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.object_material, s->object_material_indices, s->object_count)) return rc;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.spheres, reinterpret_cast<const float4*>(s->spheres), s->sphere_count)) return rc;
+  const DMaterial* mats = nullptr;
+  if (int rc = upload(ctx, ctx->scene_allocs, &mats, reinterpret_cast<const DMaterial*>(s->materials), s->material_count)) return rc;
+  d.materials = mats;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.positions, s->positions, (size_t)s->vertex_count * 3u)) return rc;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.indices, s->indices, s->index_count)) return rc;
+  // node -> two float4: {min.xyz, first}, {max.xyz, count}
+  std::vector<float4> packed((size_t)node_count * 2u);
+  for (uint32_t i = 0; i < node_count; ++i) {
+    const ptc_bvh_node& n = nodes[i];
+    float fbits, cbits;
+    std::memcpy(&fbits, &n.first_child_or_primitive, 4);
+    std::memcpy(&cbits, &n.primitive_count, 4);
+    packed[2u * i] = make_float4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], fbits);
+    packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
+  }
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) return rc;
+  d.object_count = s->object_count;
+  d.bvh_node_count = node_count;
+  ctx->scene = d;
+  ctx->has_scene = true;
+  ctx->bvh_nodes = node_count;
+  ctx->bvh_depth = depth;
+  ctx->triangles = s->index_count / 3u;
+  return PTC_OK;
+}
+
+int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
+{
+  if (!ctx || width < 2u || height < 2u) return fail(ctx, PTC_ERR_INVALID, "resolution must be at least 2x2");
+  if ((uint64_t)width * height > 0x7fffffffull) return fail(ctx, PTC_ERR_INVALID, "too many pixels");
+  if (int rc = bind_device(ctx)) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_pool(ctx->frame_allocs);
+  const size_t P = (size_t)width * height;
+  auto& pool = ctx->frame_allocs;
+  for (int k = 0; k < 2; ++k) {
+    if (int rc = dev_alloc(ctx, pool, &ctx->paths[k].o4, P)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &ctx->paths[k].d4, P)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &ctx->paths[k].t4, P)) return rc;
+  }
+  if (int rc = dev_alloc(ctx, pool, &ctx->hits.tp, P)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->hits.nm, P)) return rc;
+  const size_t chunks = (P + kChunk - 1) / kChunk;
+  if (int rc = dev_alloc(ctx, pool, &ctx->chunk_counts, chunks)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->chunk_offsets, chunks)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->fb.color4, P)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->fb.nd4, P)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->den_a, P)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->den_b, P)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->pack_buf, P * 3u)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->rgba_buf, P)) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fb.color4, 0, P * sizeof(float4), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fb.nd4, 0, P * sizeof(float4), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->den_a, 0, P * sizeof(float4), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->den_b, 0, P * sizeof(float4), ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->width = width;
+  ctx->height = height;
+  ctx->pix_begin = 0;
+  ctx->pix_count = (uint32_t)P;
+  ctx->pix_capacity = (uint32_t)P;
+  ctx->result = ctx->fb.color4;
+  ctx->have_cam = false;
+  ctx->in_frame = false;
+  return ptc_restart(ctx);
+}
+
+int ptc_set_rows(ptc_ctx* ctx, uint32_t row_begin, uint32_t row_end)
+{
+  if (!ctx || !ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
+  if (row_begin >= row_end || row_end > ctx->height) return fail(ctx, PTC_ERR_INVALID, "bad row range");
+  ctx->pix_begin = row_begin * ctx->width;
+  ctx->pix_count = (row_end - row_begin) * ctx->width;
+  return ptc_restart(ctx);
+}
+
+int ptc_restart(ptc_ctx* ctx)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  ctx->iteration = 0;
+  return PTC_OK;
+}
+
+int ptc_iteration(const ptc_ctx* ctx) { return ctx ? ctx->iteration : PTC_ERR_INVALID; }
+
+int ptc_set_iteration(ptc_ctx* ctx, int iteration)
+{
+  if (!ctx || iteration < 0) return PTC_ERR_INVALID;
+  ctx->iteration = iteration;
+  return PTC_OK;
+}
+
+int ptc_set_max_iterations(ptc_ctx* ctx, int max_iterations)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  ctx->max_iterations = max_iterations;
+  return PTC_OK;
+}
+
+int ptc_set_method(ptc_ctx* ctx, int method)
+{
+  if (!ctx || (method != PTC_METHOD_MEGAKERNEL && method != PTC_METHOD_STREAMING)) return fail(ctx, PTC_ERR_INVALID, "unknown method");
+  ctx->method = method;
+  return PTC_OK;
+}
+
+int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
+{
+  if (!ctx || max_bounces < 1 || max_bounces > (int)kMaxBounces) return fail(ctx, PTC_ERR_INVALID, "max_bounces must be in [1,64]");
+  ctx->max_bounces = max_bounces;
+  return PTC_OK;
+}
+
+int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p)
+{
+  if (!ctx || !p) return PTC_ERR_INVALID;
+  ctx->den = *p;
+  return PTC_OK;
+}
+
+static int frame_ready(ptc_ctx* ctx)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, PTC_ERR_NO_SCENE, "no scene uploaded");
+  if (!ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
+  return bind_device(ctx);
+}
+
+int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
+{
+  if (int rc = frame_ready(ctx)) return rc;
+  if (!camera) return fail(ctx, PTC_ERR_INVALID, "camera is NULL");
+  if (ctx->in_frame) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_end missing");
+  ctx->cam = make_camera(*camera, ctx->width, ctx->height);
+  ctx->have_cam = true;
+  ctx->cur = 0;
+  launch_raygen(ctx->stream, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count, ctx->paths[0], ctx->counters);
+  if (int rc = check_last(ctx, "raygen")) return rc;
+  ctx->in_frame = true;
+  return PTC_OK;
+}
+
+int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
+{
+  if (int rc = frame_ready(ctx)) return rc;
+  if (!ctx->in_frame) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (bounce < 0 || bounce >= ctx->max_bounces) return fail(ctx, PTC_ERR_INVALID, "bounce out of range");
+  const bool last = bounce == ctx->max_bounces - 1;
+  DPaths in = ctx->paths[ctx->cur], out = ctx->paths[ctx->cur ^ 1];
+  launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters);
+  launch_scan(ctx->stream, bounce, last, ctx->chunk_counts, ctx->chunk_offsets, ctx->counters);
+  launch_shade(ctx->stream, ctx->scene, in, out, ctx->hits, ctx->pix_count, (uint32_t)ctx->iteration, bounce, last,
+               slot_base_dev, ctx->chunk_offsets, ctx->fb, ctx->pix_begin, ctx->counters);
+  ctx->cur ^= 1;
+  return check_last(ctx, "bounce");
+}
+
+int ptc_trace_end(ptc_ctx* ctx)
+{
+  if (!ctx || !ctx->in_frame) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  ctx->in_frame = false;
+  ++ctx->iteration;
+  ++ctx->frames;
+  ctx->result = ctx->fb.color4;  // path_tracer.cu:476
+  return PTC_OK;
+}
+
+int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr)
+{
+  if (!ctx || !dev_ptr || bounce < 0 || bounce > (int)kMaxBounces) return PTC_ERR_INVALID;
+  *dev_ptr = &ctx->counters->live[bounce];
+  return PTC_OK;
+}
+
+int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
+{
+  if (int rc = frame_ready(ctx)) return rc;
+  if (!camera) return fail(ctx, PTC_ERR_INVALID, "camera is NULL");
+  if (ctx->iteration >= ctx->max_iterations) {  // path_tracer.cu:391
+    ctx->result = ctx->fb.color4;
+    return PTC_OK;
+  }
+  if (ctx->method == PTC_METHOD_MEGAKERNEL) {
+    ctx->cam = make_camera(*camera, ctx->width, ctx->height);
+    ctx->have_cam = true;
+    launch_megakernel(ctx->stream, ctx->scene, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count,
+                      ctx->max_bounces, ctx->fb, ctx->counters);
+    if (int rc = check_last(ctx, "megakernel")) return rc;
+    ++ctx->iteration;
+    ++ctx->frames;
+    ctx->result = ctx->fb.color4;
+    return PTC_OK;
+  }
+  if (int rc = ptc_trace_begin(ctx, camera)) return rc;
+  for (int b = 0; b < ctx->max_bounces; ++b)
+    if (int rc = ptc_trace_bounce(ctx, b, nullptr)) {
+      ctx->in_frame = false;
+      return rc;
+    }
+  return ptc_trace_end(ctx);
+}
+
+int ptc_denoise(ptc_ctx* ctx)
+{
+  if (int rc = frame_ready(ctx)) return rc;
+  if (!ctx->have_cam) return fail(ctx, PTC_ERR_INVALID, "denoise needs a traced frame (it reuses the last camera)");
+  if (ctx->pix_count != ctx->width * ctx->height) return fail(ctx, PTC_ERR_INVALID, "denoise needs the full frame in one context");
+  const DDenoise prm{ctx->den.color_weight, ctx->den.normal_weight, ctx->den.position_weight};
+  // edge_avoiding_a_trous_denoiser.cu:102-108: (color, back, front) <- (back, front, back) after each pass
+  const float4* color = ctx->fb.color4;
+  float4* back = ctx->den_a;
+  float4* front = ctx->den_b;
+  for (int step = 1; step <= ctx->den.filter_size; step *= 2) {
+    launch_denoise_pass(ctx->stream, ctx->cam, ctx->pix_begin, ctx->pix_count, color, ctx->fb.nd4, back, step, prm);
+    const float4* new_color = back;
+    float4* new_back = front;
+    float4* new_front = back;
+    color = new_color;
+    back = new_back;
+    front = new_front;
+  }
+  ctx->result = front;
+  return check_last(ctx, "denoise");
+}
+
+int ptc_present_rgba8(ptc_ctx* ctx, void* dst, int dst_is_device, int display_type)
+{
+  if (!ctx || !dst) return PTC_ERR_INVALID;
+  if (!ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
+  if (int rc = bind_device(ctx)) return rc;
+  const float4* src = nullptr;
+  int mode = 0;
+  switch (display_type) {
+  case PTC_DISPLAY_FINAL: src = ctx->result; break;
+  case PTC_DISPLAY_COLOR: src = ctx->fb.color4; break;
+  case PTC_DISPLAY_NORMAL: src = ctx->fb.nd4; mode = 1; break;
+  case PTC_DISPLAY_DEPTH: src = ctx->fb.nd4; mode = 2; break;
+  default: return fail(ctx, PTC_ERR_INVALID, "unknown display type");
+  }
+  uint32_t* out = dst_is_device ? static_cast<uint32_t*>(dst) : ctx->rgba_buf;
+  launch_preview(ctx->stream, src, ctx->pix_count, mode, out);
+  if (int rc = check_last(ctx, "preview")) return rc;
+  if (!dst_is_device)
+    HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->rgba_buf, (size_t)ctx->pix_count * 4u, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // path_tracer.cu:519
+  return PTC_OK;
+}
+
+int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device)
+{
+  if (!ctx || !dst) return PTC_ERR_INVALID;
+  if (!ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
+  if (int rc = bind_device(ctx)) return rc;
+  const float4* src = nullptr;
+  int sel = 0;
+  size_t floats = (size_t)ctx->pix_count * 3u;
+  switch (which) {
+  case PTC_BUF_COLOR: src = ctx->fb.color4; break;
+  case PTC_BUF_NORMAL: src = ctx->fb.nd4; break;
+  case PTC_BUF_DEPTH: src = ctx->fb.nd4; sel = 1; floats = ctx->pix_count; break;
+  case PTC_BUF_FINAL: src = ctx->result; break;
+  default: return fail(ctx, PTC_ERR_INVALID, "unknown buffer");
+  }
+  float* out = dst_is_device ? static_cast<float*>(dst) : ctx->pack_buf;
+  launch_pack(ctx->stream, src, ctx->pix_count, sel, out);
+  if (int rc = check_last(ctx, "pack")) return rc;
+  if (!dst_is_device) HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->pack_buf, floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PTC_OK;
+}
+
+int ptc_synchronize(ptc_ctx* ctx)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PTC_OK;
+}
+
+int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
+{
+  if (!ctx || !out) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  DeviceCounters host;
+  HIP_TRY(ctx, hipMemcpyAsync(&host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::memset(out, 0, sizeof *out);
+  out->rays_total = host.rays_total;
+  out->frames = ctx->frames;
+  for (int i = 0; i < PTC_MAX_BOUNCES_CAP; ++i) out->last_live[i] = i < ctx->max_bounces ? host.live[i] : 0u;
+  out->bvh_node_count = ctx->bvh_nodes;
+  out->bvh_max_depth = ctx->bvh_depth;
+  out->triangle_count = ctx->triangles;
+  out->stack_capacity = kStackDepth;
+  if (host.flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow during rendering");
+  return PTC_OK;
+}
+
+int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t, float* hit_normal, uint32_t* hit_material,
+                       uint8_t* hit_side)
+{
+  if (!ctx || !rays || !hit_t || !hit_normal || !hit_material || !hit_side) return PTC_ERR_INVALID;
+  if (!ctx->has_scene) return fail(ctx, PTC_ERR_NO_SCENE, "no scene uploaded");
+  if (n == 0) return PTC_OK;
+  if (int rc = bind_device(ctx)) return rc;
+  std::vector<void*> pool;
+  float4 *ro = nullptr, *rd = nullptr;
+  DHits hits{};
+  int rc = dev_alloc(ctx, pool, &ro, n);
+  if (!rc) rc = dev_alloc(ctx, pool, &rd, n);
+  if (!rc) rc = dev_alloc(ctx, pool, &hits.tp, n);
+  if (!rc) rc = dev_alloc(ctx, pool, &hits.nm, n);
+  if (rc) {
+    free_pool(pool);
+    return rc;
+  }
+  std::vector<float4> ho(n), hd(n), tp(n), nm(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* r = rays + 8u * (size_t)i;
+    ho[i] = make_float4(r[0], r[1], r[2], r[3]);
+    hd[i] = make_float4(r[4], r[5], r[6], r[7]);
+  }
+  hipError_t e = hipMemcpyAsync(ro, ho.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(rd, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->counters);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(tp.data(), hits.tp, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(nm.data(), hits.nm, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_pool(pool);
+  if (e != hipSuccess) return fail(ctx, PTC_ERR_HIP, std::string("intersect_rays: ") + hipGetErrorString(e));
+  for (uint32_t i = 0; i < n; ++i) {
+    hit_t[i] = tp[i].x;
+    hit_normal[3u * i] = nm[i].x;
+    hit_normal[3u * i + 1u] = nm[i].y;
+    hit_normal[3u * i + 2u] = nm[i].z;
+    uint32_t ms;
+    std::memcpy(&ms, &nm[i].w, 4);
+    hit_material[i] = ms & 0x7fffffffu;
+    hit_side[i] = (uint8_t)(ms >> 31);
+  }
+  return PTC_OK;
+}
+
+int ptc_build_bvh(const float* positions, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                  ptc_bvh_node* nodes, uint32_t* max_depth)
+{
+  if (!positions || !indices || !nodes || index_count % 3u) return PTC_ERR_INVALID;
+  return build_bvh(positions, vertex_count, indices, index_count, nodes, max_depth);
+}
+
+int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_sphere* sphere, const float* mesh_aabb6,
+                    ptc_object* out)
+{
+  return make_object(type, index, m16, sphere, mesh_aabb6, out);
+}
+
+int ptc_selftest_math(ptc_ctx* ctx, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,
+                      float* out_sin, float* out_cos)
+{
+  if (!ctx || !a || !b || !out_div || !out_sqrt || !out_sin || !out_cos) return PTC_ERR_INVALID;
+  if (n == 0) return PTC_OK;
+  if (int rc = bind_device(ctx)) return rc;
+  std::vector<void*> pool;
+  float* d[6] = {};
+  for (auto& p : d)
+    if (int rc = dev_alloc(ctx, pool, &p, n)) {
+      free_pool(pool);
+      return rc;
+    }
+  hipError_t e = hipMemcpyAsync(d[0], a, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d[1], b, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_selftest(ctx->stream, d[0], d[1], n, d[2], d[3], d[4], d[5]);
+    e = hipGetLastError();
+  }
+  float* outs[4] = {out_div, out_sqrt, out_sin, out_cos};
+  for (int k = 0; k < 4 && e == hipSuccess; ++k)
+    e = hipMemcpyAsync(outs[k], d[2 + k], n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_pool(pool);
+  if (e != hipSuccess) return fail(ctx, PTC_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
+  return PTC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""Python mirror of the reference's `class PathTracer` (src/lib/path_tracer.hpp:60-99) over the C ABI.
+
+Same public surface: fields ``max_iterations``, ``current_gpu_method``, ``atrous_denoiser``; methods
+``restart``, ``iteration``, ``resize_image``, ``create_buffers``, ``path_trace``, ``denoise``,
+``send_to_preview``.  Everything runs in libptcore.so on the GPU; this file only marshals arguments."""
+import ctypes as C
+from dataclasses import dataclass
+from enum import IntEnum
+
+import numpy as np
+
+from . import _capi
+from .scene_description import Camera, FlatScene, SceneDescription
+
+
+class GPUMethod(IntEnum):  # path_tracer.hpp:57
+    megakernel = 0
+    streaming = 1
+
+
+class DisplayBufferType(IntEnum):  # path_tracer.hpp:19
+    final = 0
+    color = 1
+    normal = 2
+    depth = 3
+
+
+@dataclass
+class EdgeAvoidingATrousDenoiser:  # denoising/edge_avoiding_a_trous_denoiser.hpp:7-12
+    filter_size: int = 10
+    color_weight: float = 0.45
+    normal_weight: float = 0.30
+    position_weight: float = 0.25
+
+
+class PathTracer:
+    def __init__(self, device=0, max_bounces=50):
+        self._lib = _capi.lib()
+        self.max_iterations = 1
+        self.current_gpu_method = GPUMethod.streaming
+        self.atrous_denoiser = EdgeAvoidingATrousDenoiser()
+        self.max_bounces = max_bounces  # reference: compile-time 50 (path_tracer.cu:27)
+        cfg = _capi.ptc_config(device=device, max_bounces=max_bounces, method=int(self.current_gpu_method), reserved=0)
+        handle = C.c_void_p()
+        _capi.check(self._lib.ptc_create(C.byref(cfg), C.byref(handle)))
+        self._ctx = handle
+        self._resolution = None
+        self._rows = None
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.ptc_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        return _capi.check(rc, self._ctx)
+
+    def _push_fields(self):
+        self._check(self._lib.ptc_set_max_iterations(self._ctx, int(self.max_iterations)))
+        self._check(self._lib.ptc_set_method(self._ctx, int(self.current_gpu_method)))
+        self._check(self._lib.ptc_set_max_bounces(self._ctx, int(self.max_bounces)))
+        d = self.atrous_denoiser
+        p = _capi.ptc_denoiser_params(int(d.filter_size), float(d.color_weight), float(d.normal_weight),
+                                      float(d.position_weight))
+        self._check(self._lib.ptc_set_denoiser_params(self._ctx, C.byref(p)))
+
+    # -- reference API --------------------------------------------------------------------------
+    def restart(self):
+        self._check(self._lib.ptc_restart(self._ctx))
+
+    def iteration(self):
+        return self._lib.ptc_iteration(self._ctx)
+
+    def resize_image(self, resolution):
+        w, h = resolution
+        self._check(self._lib.ptc_resize(self._ctx, int(w), int(h)))
+        self._resolution = (int(w), int(h))
+        self._rows = (0, int(h))
+
+    def create_buffers(self, resolution, scene):
+        """scene: a SceneDescription (flattened with build_scene(), like the reference) or a FlatScene."""
+        flat = scene.build_scene() if isinstance(scene, SceneDescription) else scene
+        assert isinstance(flat, FlatScene)
+        desc = flat.to_c()
+        self._check(self._lib.ptc_upload_scene(self._ctx, C.byref(desc)))
+        self.resize_image(resolution)
+
+    def path_trace(self, camera, resolution=None):
+        if resolution is not None and tuple(resolution) != self._resolution:
+            raise ValueError("resolution differs from the allocated buffers (call resize_image first)")
+        self._push_fields()
+        cam = camera.to_c() if isinstance(camera, Camera) else camera
+        self._check(self._lib.ptc_trace(self._ctx, C.byref(cam)))
+
+    def denoise(self, resolution=None):
+        self._push_fields()
+        self._check(self._lib.ptc_denoise(self._ctx))
+
+    def send_to_preview(self, dev_pbo=None, resolution=None, display_type=DisplayBufferType.final):
+        """With dev_pbo=None returns an [h, w, 4] uint8 array; otherwise writes RGBA8 to the device pointer."""
+        if dev_pbo is not None:
+            self._check(self._lib.ptc_present_rgba8(self._ctx, C.c_void_p(int(dev_pbo)), 1, int(display_type)))
+            return None
+        out = np.empty((self.pixel_count(), 4), dtype=np.uint8)
+        self._check(self._lib.ptc_present_rgba8(self._ctx, out.ctypes.data_as(C.c_void_p), 0, int(display_type)))
+        return out.reshape(self._rows[1] - self._rows[0], self._resolution[0], 4)
+
+    # -- additions (no reference equivalent) ----------------------------------------------------------
+    def set_rows(self, row_begin, row_end):
+        self._check(self._lib.ptc_set_rows(self._ctx, int(row_begin), int(row_end)))
+        self._rows = (int(row_begin), int(row_end))
+
+    def pixel_count(self):
+        return (self._rows[1] - self._rows[0]) * self._resolution[0]
+
+    def set_iteration(self, it):
+        self._check(self._lib.ptc_set_iteration(self._ctx, int(it)))
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.ptc_set_stream(self._ctx, C.c_void_p(int(hip_stream)) if hip_stream else None))
+
+    def trace_begin(self, camera):
+        self._push_fields()
+        cam = camera.to_c() if isinstance(camera, Camera) else camera
+        self._check(self._lib.ptc_trace_begin(self._ctx, C.byref(cam)))
+
+    def trace_bounce(self, bounce, slot_base_dev=None):
+        self._check(self._lib.ptc_trace_bounce(self._ctx, int(bounce), C.c_void_p(int(slot_base_dev)) if slot_base_dev else None))
+
+    def trace_end(self):
+        self._check(self._lib.ptc_trace_end(self._ctx))
+
+    def live_count_dev(self, bounce):
+        p = C.c_void_p()
+        self._check(self._lib.ptc_live_count_dev(self._ctx, int(bounce), C.byref(p)))
+        return p.value
+
+    def synchronize(self):
+        self._check(self._lib.ptc_synchronize(self._ctx))
+
+    def download(self, which):
+        """which: 'color' | 'normal' | 'depth' | 'final' -> float32 array [rows, w, 3] (or [rows, w] for depth)."""
+        sel = {"color": _capi.BUF_COLOR, "normal": _capi.BUF_NORMAL, "depth": _capi.BUF_DEPTH, "final": _capi.BUF_FINAL}[which]
+        n = self.pixel_count()
+        ch = 1 if which == "depth" else 3
+        out = np.empty(n * ch, dtype=np.float32)
+        self._check(self._lib.ptc_download(self._ctx, sel, out.ctypes.data_as(C.c_void_p), 0))
+        rows, w = self._rows[1] - self._rows[0], self._resolution[0]
+        return out.reshape(rows, w) if ch == 1 else out.reshape(rows, w, 3)
+
+    def download_to_device(self, which, dev_ptr):
+        sel = {"color": _capi.BUF_COLOR, "normal": _capi.BUF_NORMAL, "depth": _capi.BUF_DEPTH, "final": _capi.BUF_FINAL}[which]
+        self._check(self._lib.ptc_download(self._ctx, sel, C.c_void_p(int(dev_ptr)), 1))
+
+    def stats(self):
+        s = _capi.ptc_stats()
+        self._check(self._lib.ptc_get_stats(self._ctx, C.byref(s)))
+        return {"rays_total": int(s.rays_total), "frames": int(s.frames),
+                "last_live": [int(x) for x in s.last_live[: self.max_bounces]],
+                "bvh_node_count": int(s.bvh_node_count), "bvh_max_depth": int(s.bvh_max_depth),
+                "triangle_count": int(s.triangle_count), "stack_capacity": int(s.stack_capacity)}
+
+    def intersect_rays(self, rays):
+        """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = len(rays)
+        t = np.empty(n, dtype=np.float32)
+        nrm = np.empty((n, 3), dtype=np.float32)
+        mat = np.empty(n, dtype=np.uint32)
+        side = np.empty(n, dtype=np.uint8)
+        self._check(self._lib.ptc_intersect_rays(
+            self._ctx, rays.ctypes.data_as(C.POINTER(C.c_float)), n, t.ctypes.data_as(C.POINTER(C.c_float)),
+            nrm.ctypes.data_as(C.POINTER(C.c_float)), mat.ctypes.data_as(C.POINTER(C.c_uint32)),
+            side.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return t, nrm, mat, side
+
+    def selftest_math(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        outs = [np.empty_like(a) for _ in range(4)]
+        fp = C.POINTER(C.c_float)
+        self._check(self._lib.ptc_selftest_math(self._ctx, a.ctypes.data_as(fp), b.ctypes.data_as(fp), len(a),
+                                                *[o.ctypes.data_as(fp) for o in outs]))
+        return outs

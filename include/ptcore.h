@@ -1,0 +1,224 @@
+/*
+ * ptcore.h -- C ABI of libptcore.so, the MI355X (gfx950) path-tracing core.
+ *
+ * This is the drop-in boundary for the render core of LesleyLai/cuda-path-tracer: one `ptc_ctx`
+ * replaces one `class PathTracer` (reference src/lib/path_tracer.hpp:60-99) together with the
+ * device-side `Scene` it owns (src/lib/scene.hpp:25-67).  Each entry point names the reference
+ * interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns PTC_OK (0) or a negative ptc_status; nothing calls exit()
+ *     (the reference's CUDA_CHECK / panic abort the process: cuda_utils/cuda_check.cpp:7-23,
+ *     prelude.cpp:5-10);  ptc_last_error() gives the message of the last failure.
+ *   - one context = one GPU = one host thread at a time (same as the reference, which is
+ *     single-threaded on the default stream).
+ *   - matrices are column-major float[16] (glm layout): m[4*col + row].
+ *   - framebuffers are row-major, row 0 = top of the view, flat index = x + y*width
+ *     (cuda_utils/indices.cuh:20-26).
+ *   - there is NO CPU fallback: every call that needs the GPU fails with PTC_ERR_NO_DEVICE /
+ *     PTC_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTC_ABI_VERSION 1
+
+typedef enum ptc_status {
+  PTC_OK = 0,
+  PTC_ERR_INVALID = -1,       /* bad argument / bad call order */
+  PTC_ERR_NO_DEVICE = -2,     /* no usable HIP device */
+  PTC_ERR_HIP = -3,           /* a HIP runtime call or kernel failed */
+  PTC_ERR_OOM = -4,
+  PTC_ERR_BVH = -5,           /* BVH build failed (empty SAH side: bvh.cpp:84-85) */
+  PTC_ERR_STACK = -6,         /* traversal stack overflow (reference: UB beyond depth 24, static_stack.hpp:21-25) */
+  PTC_ERR_NO_SCENE = -7
+} ptc_status;
+
+/* GPUMethod, path_tracer.hpp:57 */
+typedef enum ptc_method { PTC_METHOD_MEGAKERNEL = 0, PTC_METHOD_STREAMING = 1 } ptc_method;
+
+/* DisplayBufferType, path_tracer.hpp:19 */
+typedef enum ptc_display { PTC_DISPLAY_FINAL = 0, PTC_DISPLAY_COLOR = 1, PTC_DISPLAY_NORMAL = 2, PTC_DISPLAY_DEPTH = 3 } ptc_display;
+
+/* which accumulated framebuffer ptc_download reads */
+typedef enum ptc_buffer { PTC_BUF_COLOR = 0, PTC_BUF_NORMAL = 1, PTC_BUF_DEPTH = 2, PTC_BUF_FINAL = 3 } ptc_buffer;
+
+/* ObjectType + GPUObject, scene.hpp:14-22.  Same 160-byte layout as the reference. */
+typedef struct ptc_object {
+  uint32_t type;      /* 0 sphere, 1 mesh */
+  uint32_t index;     /* sphere index; 0 for meshes (scene_description.cpp:42) */
+  float m[16];        /* Transform::m_ */
+  float inv_m[16];    /* Transform::inverse_m_ */
+  float aabb_min[3];  /* world-space AABB */
+  float aabb_max[3];
+} ptc_object;
+
+/* Sphere, sphere.hpp:8-11 */
+typedef struct ptc_sphere { float center[3]; float radius; } ptc_sphere;
+
+/* Material, material.hpp:19-38 (20 bytes).  type 0 Diffuse {albedo rgb}, 1 Metal {albedo rgb, fuzz},
+ * 2 Dielectric {refraction_index} */
+typedef struct ptc_material { int32_t type; float p[4]; } ptc_material;
+
+/* BVHNode, accelerators/bvh.hpp:17-28 (32 bytes).  leaf <=> primitive_count != 0; for a leaf
+ * first_child_or_primitive is the offset of its triangle in the index array (multiple of 3); for an
+ * inner node it is the left child, the right child is +1. */
+typedef struct ptc_bvh_node {
+  float aabb_min[3];
+  float aabb_max[3];
+  uint32_t first_child_or_primitive;
+  uint32_t primitive_count;
+} ptc_bvh_node;
+
+/* The flat arrays SceneDescription::build_scene() uploads with six cudaMemcpy calls
+ * (scene_description.cpp:54-114).  Host pointers; copied during ptc_upload_scene. */
+typedef struct ptc_scene_desc {
+  const ptc_object* objects;
+  uint32_t object_count;
+  const uint32_t* object_material_indices; /* object_count entries */
+  const ptc_sphere* spheres;
+  uint32_t sphere_count;
+  const ptc_material* materials;
+  uint32_t material_count;
+  const float* positions;                  /* 3 floats per vertex */
+  uint32_t vertex_count;
+  const uint32_t* indices;                 /* 3 per triangle */
+  uint32_t index_count;
+  const ptc_bvh_node* bvh;                 /* optional: NULL -> built by ptc_upload_scene */
+  uint32_t bvh_node_count;
+} ptc_scene_desc;
+
+/* Camera, camera.hpp:17-23 */
+typedef struct ptc_camera {
+  float position[3];
+  float rotation_wxyz[4]; /* glm::quat, default {1,0,0,0} */
+  float vfov;             /* radians */
+} ptc_camera;
+
+/* EdgeAvoidingATrousDenoiser's public fields, denoising/edge_avoiding_a_trous_denoiser.hpp:9-12 */
+typedef struct ptc_denoiser_params {
+  int32_t filter_size;   /* default 10 */
+  float color_weight;    /* default 0.45 */
+  float normal_weight;   /* default 0.30 */
+  float position_weight; /* default 0.25 */
+} ptc_denoiser_params;
+
+typedef struct ptc_config {
+  int32_t device;       /* HIP device ordinal (the reference never selects one: cli.cpp:71-78) */
+  int32_t max_bounces;  /* reference: compile-time 50 (path_tracer.cu:27); <=0 -> 50 */
+  int32_t method;       /* ptc_method; default streaming (path_tracer.hpp:64) */
+  int32_t reserved;
+} ptc_config;
+
+#define PTC_MAX_BOUNCES_CAP 64
+
+typedef struct ptc_stats {
+  uint64_t rays_total;                       /* closest-hit queries since ptc_restart / create */
+  uint64_t frames;                           /* ptc_trace calls that rendered since then */
+  uint32_t last_live[PTC_MAX_BOUNCES_CAP];   /* live paths entering each bounce of the last streaming frame */
+  uint32_t bvh_node_count;
+  uint32_t bvh_max_depth;
+  uint32_t triangle_count;
+  uint32_t stack_capacity;                   /* traversal stack entries available per ray */
+} ptc_stats;
+
+typedef struct ptc_ctx ptc_ctx;
+
+/* ---- lifetime ---- */
+int ptc_abi_version(void);
+int ptc_device_count(int* count);                                   /* cli.cpp:72-73 cudaGetDeviceCount */
+int ptc_create(const ptc_config* config, ptc_ctx** out);            /* PathTracer::PathTracer(), path_tracer.cu:387 */
+void ptc_destroy(ptc_ctx* ctx);                                     /* ~PathTracer (cuda::Buffer dtors, cuda_buffer.hpp:20) */
+const char* ptc_last_error(const ptc_ctx* ctx);                     /* ctx may be NULL: last ptc_create failure */
+
+/* Use an externally owned HIP stream (hipStream_t as void*), e.g. torch's current stream, for all
+ * kernels of this context.  NULL restores the context's own stream. */
+int ptc_set_stream(ptc_ctx* ctx, void* hip_stream);
+
+/* ---- scene + buffers ---- */
+/* Upload half of PathTracer::create_buffers (path_tracer.cu:559-564) = SceneDescription::build_scene's
+ * device uploads.  An empty mesh (index_count == 0) is accepted (the reference panics, bvh.cpp:200). */
+int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* scene);
+/* PathTracer::resize_image (path_tracer.cu:527-545): (re)allocates all per-pixel buffers, restarts. */
+int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height);
+/* Render only image rows [row_begin,row_end) of the width x height frame (multi-GPU row bands;
+ * no reference equivalent).  Must follow ptc_resize.  Default: all rows. */
+int ptc_set_rows(ptc_ctx* ctx, uint32_t row_begin, uint32_t row_end);
+int ptc_restart(ptc_ctx* ctx);                                      /* PathTracer::restart, path_tracer.cu:522-525 */
+int ptc_iteration(const ptc_ctx* ctx);                              /* PathTracer::iteration(), path_tracer.hpp:88 */
+int ptc_set_iteration(ptc_ctx* ctx, int iteration);                 /* test hook: continue from a given sample index */
+
+/* public mutable fields of PathTracer (path_tracer.hpp:62-66) */
+int ptc_set_max_iterations(ptc_ctx* ctx, int max_iterations);       /* PathTracer::max_iterations (default 1) */
+int ptc_set_method(ptc_ctx* ctx, int method);                       /* PathTracer::current_gpu_method */
+int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces);             /* static max_bounces = 50, path_tracer.cu:27 */
+int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* PathTracer::atrous_denoiser */
+
+/* ---- the hot path ---- */
+/* PathTracer::path_trace (path_tracer.cu:389-477): one sample per pixel, accumulated as a running
+ * mean; no-op once iteration() >= max_iterations.  Asynchronous on the context's stream. */
+int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera);
+
+/* The same frame in three steps, for callers that must exchange live-path counts between bounces
+ * (multi-GPU row bands keep the reference's global slot numbering this way):
+ *   ptc_trace_begin   = generate_rays (ray_gen.cu:63-79)
+ *   ptc_trace_bounce  = intersection_kernel + material_kernel + stable_partition for bounce b
+ *                       (path_tracer.cu:423-457); slot_base_dev (device pointer to ONE uint32, or
+ *                       NULL for 0) is added to every local slot index before RNG seeding
+ *   ptc_trace_end     = final_gathering_kernel (path_tracer.cu:460-470) + ++iteration
+ * ptc_live_count_dev returns the device address of the uint32 holding the number of live paths
+ * entering bounce b of the current frame (valid after bounce b-1 was enqueued). */
+int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera);
+int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev);
+int ptc_trace_end(ptc_ctx* ctx);
+int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr);
+
+/* PathTracer::denoise (path_tracer.cu:479-485) */
+int ptc_denoise(ptc_ctx* ctx);
+
+/* PathTracer::send_to_preview (path_tracer.cu:487-520): tonemap to RGBA8 (4 bytes/pixel, rows of
+ * this context only).  dst is a device pointer if dst_is_device != 0 (the reference always writes a
+ * device/managed pointer), else host memory.  Synchronises like the reference. */
+int ptc_present_rgba8(ptc_ctx* ctx, void* dst, int dst_is_device, int display_type);
+
+/* Copy an accumulated float framebuffer (rows of this context only) as packed floats: 3 per pixel
+ * for COLOR/NORMAL/FINAL (glm::vec3 layout of dev_color_buffer_ etc., path_tracer.hpp:73-81),
+ * 1 per pixel for DEPTH.  Synchronises. */
+int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device);
+
+int ptc_synchronize(ptc_ctx* ctx);                                  /* cudaDeviceSynchronize at cli.cpp:100 */
+int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out);                    /* synchronises */
+
+/* ---- pieces exposed for parity tests and for host-side callers ---- */
+/* intersection_kernel alone (path_tracer.cu:271-290) on caller-supplied rays (host arrays of
+ * 8 floats: origin, t_min, direction, t_max = struct Ray, ray.hpp:8-20).  Outputs (host):
+ * hit_t[n] (t, or -1 on miss), hit_normal[3n], hit_material[n], hit_side[n]. */
+int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t, float* hit_normal,
+                       uint32_t* hit_material, uint8_t* hit_side);
+
+/* bvh_from_mesh (accelerators/bvh.cpp:211-253), host-side, no GPU needed.  nodes must hold
+ * index_count/3*2-1 entries.  Returns the node count (>0) or a negative ptc_status. */
+int ptc_build_bvh(const float* positions, uint32_t vertex_count, const uint32_t* indices,
+                  uint32_t index_count, ptc_bvh_node* nodes, uint32_t* max_depth);
+
+/* Per-object part of SceneDescription::build_scene (scene_description.cpp:17-52): fills inv_m
+ * (glm::inverse) and the world AABB.  sphere / mesh_aabb6 (min xyz, max xyz) as the type needs. */
+int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_sphere* sphere,
+                    const float* mesh_aabb6, ptc_object* out);
+
+/* Device self-test of the arithmetic contract the parity tests rely on: evaluates IEEE divide,
+ * sqrt and the deterministic sin/cos on the GPU for n inputs (host arrays in, host arrays out). */
+int ptc_selftest_math(ptc_ctx* ctx, const float* a, const float* b, uint32_t n, float* out_div,
+                      float* out_sqrt, float* out_sin, float* out_cos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */
