@@ -96,7 +96,8 @@ struct Builder {
 
     if (n == 2) {
       uint32_t a = tris[0], b = tris[1];
-      if (comp(tri_center[a], axis) > comp(tri_center[b], axis)) std::swap(a, b);
+      const float ka = comp(tri_center[a], axis), kb = comp(tri_center[b], axis);
+      if (ka > kb || (ka == kb && a > b)) std::swap(a, b);  // tie: lower triangle index goes left
       const uint32_t l = leaf(a), r = leaf(b);
       return (int32_t)inner(l, r);
     }

@@ -592,7 +592,10 @@ static int32_t bb_build(BBuild* bb, uint32_t* tris, uint32_t n)
   if (n == 1) return (int32_t)bb_new_leaf(bb, tris[0]);
   if (n == 2) {
     uint32_t l = tris[0], r = tris[1];
-    if (vcomp(bb->leaf_center[l], axis) > vcomp(bb->leaf_center[r], axis)) { uint32_t t = l; l = r; r = t; }
+    const float kl = vcomp(bb->leaf_center[l], axis), kr = vcomp(bb->leaf_center[r], axis);
+    /* bvh.cpp:88-90 swaps when left > right; on a tie the reference keeps whatever order
+     * std::ranges::partition left behind (implementation-defined) -- here the lower triangle index goes left */
+    if (kl > kr || (kl == kr && l > r)) { uint32_t t = l; l = r; r = t; }
     uint32_t ln = bb_new_leaf(bb, l);
     uint32_t rn = bb_new_leaf(bb, r);
     return (int32_t)bb_new_inner(bb, ln, rn);

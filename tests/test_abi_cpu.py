@@ -1,0 +1,131 @@
+"""CPU-side checks of the product library: it loads, exports exactly what include/ptcore.h declares,
+its GPU-free host functions (BVH builder, object flattening) agree with the oracle bit for bit, and
+GPU entry points fail loudly (no CPU fallback) when there is no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ptcore.h but not exported by libptcore.so"
+    assert set(names) == set(pkg._capi.SIGNATURES), "ctypes binding and header disagree"
+    assert lib.ptc_abi_version() == 1
+
+
+def test_struct_layouts_match_reference_sizes(pkg):
+    c = pkg._capi
+    assert C.sizeof(c.ptc_object) == 160      # GPUObject, scene.hpp:16-22
+    assert C.sizeof(c.ptc_sphere) == 16       # Sphere, sphere.hpp:8-11
+    assert C.sizeof(c.ptc_material) == 20     # Material, material.hpp:19-38
+    assert C.sizeof(c.ptc_bvh_node) == 32     # static_assert in bvh.hpp:30
+    assert C.sizeof(c.ptc_camera) == 32
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device path")
+def test_no_device_fails_loudly(pkg):
+    with pytest.raises(pkg.PtcError) as e:
+        pkg.PathTracer()
+    assert e.value.code == pkg._capi.PTC_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("mesh_name", ["grid9x5", "grid33x17", "sphere8x16", "sphere24x48", "grid_ties"])
+def test_host_bvh_builder_equals_oracle(pkg, orc, mesh_name):
+    mesh = {
+        "grid9x5": lambda: pkg.scenes.heightfield_mesh(9, 5, 2.0, 1.0, seed=1),
+        "grid33x17": lambda: pkg.scenes.heightfield_mesh(33, 17, 8.0, 4.0, seed=7),
+        "sphere8x16": lambda: pkg.scenes.displaced_sphere_mesh(8, 16),
+        "sphere24x48": lambda: pkg.scenes.displaced_sphere_mesh(24, 48),
+        # flat regular grid: many exactly equal centroids along the split axis (tie rule)
+        "grid_ties": lambda: pkg.Mesh(*_flat_grid(17, 9)),
+    }[mesh_name]()
+    got, got_depth = pkg.bvh_from_mesh(mesh)
+    want, want_depth = orc.build_bvh(mesh.positions, mesh.indices)
+    assert got_depth == want_depth
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def _flat_grid(nx, nz):
+    m_x, m_z = np.meshgrid(np.arange(nx, dtype=np.float32), np.arange(nz, dtype=np.float32), indexing="xy")
+    pos = np.stack([m_x, 0.01 * ((m_x * 7 + m_z * 3) % 5), m_z], axis=-1).reshape(-1, 3)
+    v = (np.arange(nz - 1)[:, None] * nx + np.arange(nx - 1)[None, :]).astype(np.uint32)
+    idx = np.stack([np.stack([v, v + nx, v + 1], -1), np.stack([v + 1, v + nx, v + nx + 1], -1)], axis=2).reshape(-1)
+    return pos, idx
+
+
+def test_host_bvh_builder_errors(pkg):
+    lib = pkg.lib()
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    idx = np.tile(np.array([0, 1, 2], dtype=np.uint32), 6)
+    nodes = np.zeros(11, dtype=pkg.scene_description.BVH_NODE_DTYPE)
+    fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    rc = lib.ptc_build_bvh(pos.ctypes.data_as(fp), 3, idx.ctypes.data_as(up), len(idx),
+                           nodes.ctypes.data_as(C.POINTER(pkg._capi.ptc_bvh_node)), None)
+    assert rc == pkg._capi.PTC_ERR_BVH       # coincident centroids (reference panics, bvh.cpp:84-85)
+    bad = np.array([0, 1, 7], dtype=np.uint32)
+    rc = lib.ptc_build_bvh(pos.ctypes.data_as(fp), 3, bad.ctypes.data_as(up), 3,
+                           nodes.ctypes.data_as(C.POINTER(pkg._capi.ptc_bvh_node)), None)
+    assert rc == pkg._capi.PTC_ERR_INVALID   # vertex index out of range
+
+
+def test_make_object_equals_oracle(pkg, orc):
+    """scene_description.cpp:17-52 on both sides: glm::inverse, sphere AABB, transform_aabb"""
+    glm = pkg.glmlite
+    lib, L = pkg.lib(), orc.lib()
+    transforms = [
+        glm.identity(), glm.translate((1.0, -0.5, -2.0)),
+        glm.compose([glm.scale(0.5), glm.translate((-1.0, -0.5, -2.0))]),
+        glm.compose([glm.translate((-0.053126335, 0.030193329, 17.283958)), glm.scale(0.2),
+                     glm.rotate(np.float32(np.radians(150.0)), (0, 1, 0)), glm.translate((0, 0, -0.25))]),
+        glm.compose([glm.rotate(np.float32(0.7), (1, 2, 3)), glm.scale((1.5, 0.25, 3.0)), glm.translate((3, 4, 5))]),
+    ]
+    fp = C.POINTER(C.c_float)
+    for m in transforms:
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        sp = pkg._capi.ptc_sphere()
+        sp.center[:] = [0.1, -0.2, 0.3]
+        sp.radius = 0.75
+        box = np.array([-1, -2, -3, 1.5, 2.5, 3.5], dtype=np.float32)
+        for typ in (0, 1):
+            got = pkg._capi.ptc_object()
+            assert lib.ptc_make_object(typ, 4, m.ctypes.data_as(fp), C.byref(sp) if typ == 0 else None,
+                                       box.ctypes.data_as(fp) if typ == 1 else None, C.byref(got)) == 0
+            want = np.zeros(160, dtype=np.uint8)
+            L.orc_make_object(typ, 4, m.ctypes.data, C.addressof(sp) if typ == 0 else None,
+                              box.ctypes.data if typ == 1 else None, want.ctypes.data)
+            assert bytes(got) == want.tobytes()
+    # the inverse really is one
+    inv = np.frombuffer(bytes(got), dtype=np.float32)[18:34].reshape(4, 4)
+    assert np.allclose(pkg.glmlite.matmul(m, inv), np.eye(4), atol=1e-5)
+
+
+def test_invalid_arguments_return_error_codes(pkg):
+    lib = pkg.lib()
+    assert lib.ptc_create(None, None) == pkg._capi.PTC_ERR_INVALID
+    assert lib.ptc_restart(None) == pkg._capi.PTC_ERR_INVALID
+    assert lib.ptc_iteration(None) == pkg._capi.PTC_ERR_INVALID
+    assert lib.ptc_make_object(2, 0, None, None, None, None) == pkg._capi.PTC_ERR_INVALID
+    lib.ptc_destroy(None)  # no-op

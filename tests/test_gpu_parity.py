@@ -1,0 +1,250 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libptcore.so), against the CPU oracle
+and the committed golden frames.
+
+Stated tolerance (BASELINE.md / SURVEY.md section 8c): mean over pixels of the squared RGB error < 1e-4 on
+linear radiance, per-bounce live counts within 0.1 %, per-ray hit/miss exact and t within 4 ulp.
+Because both sides evaluate the same IEEE binary32 operations in the same order (see pt_kernels.hip),
+the results observed are bit-identical; the tests assert the stated tolerance AND report/assert exactness
+where the design guarantees it."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_MSE = 1e-4
+
+
+def mse(a, b):
+    return float(np.mean(np.sum((a.astype(np.float64) - b.astype(np.float64)) ** 2, axis=-1)))
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def _golden_scenes(golden_dir):
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.golden_scenes()
+
+
+def render(pkg, scene, flat, w, h, iters, max_bounces, method=None, denoise=False):
+    with pkg.PathTracer(device=0, max_bounces=max_bounces) as pt:
+        if method is not None:
+            pt.current_gpu_method = method
+        pt.create_buffers((w, h), flat)
+        pt.max_iterations = iters
+        live = []
+        for _ in range(iters):
+            pt.path_trace(scene.camera, (w, h))
+            live.append(pt.stats()["last_live"])
+        out = {k: pt.download(k) for k in ("color", "normal", "depth")}
+        out["live"] = np.array(live, dtype=np.uint32)
+        out["stats"] = pt.stats()
+        if denoise:
+            pt.denoise((w, h))
+            out["final"] = pt.download("final")
+        out["rgba"] = pt.send_to_preview()
+    return out
+
+
+def test_device_arithmetic_contract(pkg, orc):
+    """IEEE divide / sqrt and the deterministic sin/cos give the host's bits on gfx950."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(0, 2 * np.pi, 50000), rng.uniform(0, 1e6, 1000), [0, 1e-30, 1e-40, 3.4e38]]).astype(np.float32)
+    b = np.concatenate([rng.normal(size=50000), rng.uniform(-1e-3, 1e-3, 1000), [1e-40, 3e38, 1, 2e-39]]).astype(np.float32)
+    with pkg.PathTracer() as pt:
+        d, s, si, co = pt.selftest_math(a, b)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(d.view(np.uint32), (a / b).view(np.uint32))
+        assert np.array_equal(s.view(np.uint32), np.sqrt(a).view(np.uint32))
+    sv, cv = C.c_float(), C.c_float()
+    L = orc.lib()
+    for i in range(0, len(a), 7):
+        L.orc_sincos(float(a[i]), C.byref(sv), C.byref(cv))
+        assert np.float32(sv.value).view(np.uint32) == si[i].view(np.uint32)
+        assert np.float32(cv.value).view(np.uint32) == co[i].view(np.uint32)
+
+
+def _random_rays(rng, n, center, radius):
+    """rays aimed at a ball around the scene, from outside and from inside"""
+    o = rng.normal(size=(n, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(0.2, 3.0, size=(n, 1)) * radius + center
+    target = rng.uniform(-1, 1, size=(n, 3)) * radius * 0.7 + center
+    d = target - o
+    norm = rng.uniform(0.5, 2.0, size=(n, 1))  # un-normalised directions too (metal scatter leaves them so)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True) * norm
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = o
+    rays[:, 3] = np.where(rng.uniform(size=n) < 0.5, 1e-4, 1e-5)
+    rays[:, 4:7] = d
+    rays[:, 7] = np.where(rng.uniform(size=n) < 0.8, np.finfo(np.float32).max, rng.uniform(0.5, 6.0, size=n))
+    return rays
+
+
+@pytest.mark.parametrize("name", ["spheres", "mesh", "heightfield"])
+def test_intersection_kernel_per_ray(pkg, orc, golden_dir, name):
+    """intersection_kernel alone (path_tracer.cu:271-290): hit/miss exact, t within 4 ulp (observed: 0)."""
+    scene, w, h = _golden_scenes(golden_dir)[name]
+    flat = scene.build_scene()
+    rays = _random_rays(np.random.default_rng(42), 20000, np.array([0, -0.2, 0.0]), 2.0)
+    recs, hit = orc.intersect_rays(flat, rays)
+    with pkg.PathTracer() as pt:
+        pt.create_buffers((w, h), flat)
+        t, nrm, mat, side = pt.intersect_rays(rays)
+    assert 0.2 < hit.mean() < 1.0
+    assert np.array_equal(t >= 0, hit.astype(bool))
+    m = hit.astype(bool)
+    assert ulp_diff(t[m], recs["t"][m]).max() <= 4
+    assert np.array_equal(t[m], recs["t"][m])
+    assert np.array_equal(nrm[m], recs["normal"][m])
+    assert np.array_equal(mat[m], recs["material_id"][m].astype(np.uint32))
+    assert np.array_equal(side[m], recs["side"][m])
+    assert np.all(t[~m] == -1.0)
+
+
+@pytest.mark.parametrize("name", ["spheres", "mesh", "heightfield"])
+@pytest.mark.parametrize("mb", [4, 8, 50])
+def test_frames_against_golden(pkg, golden_dir, name, mb):
+    """4 accumulated iterations against tests/golden/frames.npz (no oracle run needed)."""
+    frames = np.load(os.path.join(golden_dir, "frames.npz"))
+    scene, w, h = _golden_scenes(golden_dir)[name]
+    out = render(pkg, scene, scene.build_scene(), w, h, 4, mb)
+    assert mse(out["color"], frames[f"{name}_mb{mb}_color"]) < TOL_MSE
+    want_live = frames[f"{name}_mb{mb}_live"].astype(np.int64)
+    assert np.all(np.abs(out["live"].astype(np.int64) - want_live) <= np.ceil(1e-3 * want_live))
+    # by construction: identical
+    for k in ("color", "normal", "depth", "live"):
+        assert np.array_equal(out[k], frames[f"{name}_mb{mb}_{k}"]), k
+    assert out["stats"]["rays_total"] == int(frames[f"{name}_mb{mb}_rays"][0])
+
+
+@pytest.mark.parametrize("cfg", [
+    ("config1", lambda p: p.scenes.cornell_spheres((256, 256)), 256, 256, 4, 4),           # config 1 at full size, 4 of 16 spp
+    ("config2_small", lambda p: p.scenes.cornell_bunny((320, 180), n_lat=36, n_lon=72), 320, 180, 2, 8),
+    ("config3_small", lambda p: p.scenes.heightfield_scene((320, 180), nx=201, nz=101), 320, 180, 3, 8),
+    ("rotated_camera", lambda p: _rotated(p), 96, 64, 2, 8),
+])
+def test_frames_against_oracle(pkg, orc, cfg):
+    name, make, w, h, iters, mb = cfg
+    scene = make(pkg)
+    flat = scene.build_scene()
+    out = render(pkg, scene, flat, w, h, iters, mb)
+    ref = orc.render_streaming(flat, scene.camera, w, h, 0, iters, mb)
+    err = mse(out["color"], ref["color"])
+    bad = float(np.mean(np.linalg.norm(out["color"] - ref["color"], axis=-1) > 1e-3))
+    print(f"{name}: mse={err:.3e} frac(|dRGB|>1e-3)={bad:.3e} rays={out['stats']['rays_total']}")
+    assert err < TOL_MSE
+    assert np.all(np.abs(out["live"].astype(np.int64) - ref["live"].astype(np.int64)) <= np.ceil(1e-3 * ref["live"]))
+    for k in ("color", "normal", "depth", "live"):
+        assert np.array_equal(out[k], ref[k]), k
+    assert out["stats"]["rays_total"] == ref["rays"]
+
+
+def _rotated(pkg):
+    """off-axis camera quaternion + scaled / rotated instances: exercises mat4_cast, inverse_transform_ray"""
+    glm = pkg.glmlite
+    s = pkg.scenes.cornell_bunny((96, 64), n_lat=10, n_lon=20)
+    mesh = list(s.mesh_map_.values())[0]
+    s.add_object(mesh, glm.compose([glm.rotate(np.float32(0.6), (0.3, 1.0, 0.2)), glm.scale((0.7, 0.4, 0.9)),
+                                    glm.translate((0.1, 0.2, 0.5))]), "glass")
+    q = np.array([0.9, 0.1, 0.3, -0.05])
+    q = q / np.linalg.norm(q)
+    s.camera = pkg.Camera(position=(0.8, 0.3, 3.5), rotation=tuple(float(v) for v in q), vfov=float(np.radians(55.0)))
+    return s
+
+
+def test_megakernel_against_oracle(pkg, orc, golden_dir):
+    """path_tracing_mega_kernel (path_tracer.cu:227-269)"""
+    for name, (scene, w, h) in _golden_scenes(golden_dir).items():
+        flat = scene.build_scene()
+        out = render(pkg, scene, flat, w, h, 2, 8, method=pkg.GPUMethod.megakernel)
+        ref = orc.render_megakernel(flat, scene.camera, w, h, 0, 2, 8)
+        assert mse(out["color"], ref["color"]) < TOL_MSE
+        for k in ("color", "normal", "depth"):
+            assert np.array_equal(out[k], ref[k]), (name, k)
+        assert out["stats"]["rays_total"] == ref["rays"]
+
+
+def test_denoise_and_preview_against_oracle(pkg, orc):
+    """denoising_kernel x4 passes + preview_kernel.  expf/powf come from different math libraries on the
+    two sides, so these are tolerance checks: |d| <= 1e-5 on the denoised radiance, 1 LSB on RGBA8.
+    Pixels whose value depends on the reference's out-of-bounds row H are excluded (undefined there)."""
+    scene = pkg.scenes.heightfield_scene((96, 64), nx=65, nz=33)
+    flat = scene.build_scene()
+    out = render(pkg, scene, flat, 96, 64, 2, 8, denoise=True)
+    ref = orc.render_streaming(flat, scene.camera, 96, 64, 0, 2, 8)
+    den, touched = orc.denoise(scene.camera, 96, 64, ref["color"], ref["normal"], ref["depth"])
+    ok = ~touched
+    assert ok.mean() > 0.4
+    assert np.max(np.abs(out["final"][ok] - den[ok])) <= 1e-5
+    # display of the denoised buffer (DisplayBufferType::final after denoise, path_tracer.cu:498-502)
+    want = orc.preview(den, 96, 64, 0)
+    got = out["rgba"]
+    assert np.max(np.abs(got[ok].astype(int) - want[ok].astype(int))) <= 1
+    assert np.all(got[..., 3] == 255)
+    with pkg.PathTracer(max_bounces=8) as pt:
+        pt.create_buffers((96, 64), flat)
+        pt.path_trace(scene.camera)
+        nrm = pt.send_to_preview(display_type=pkg.DisplayBufferType.normal)
+        dep = pt.send_to_preview(display_type=pkg.DisplayBufferType.depth)
+        n1 = pt.download("normal")
+        d1 = pt.download("depth")
+    assert np.max(np.abs(nrm.astype(int) - orc.preview(n1, 96, 64, 1).astype(int))) <= 1
+    want_d = orc.preview(d1, 96, 64, 2)
+    assert np.max(np.abs(dep.astype(int) - want_d.astype(int))) <= 1 and np.all(dep[..., 3] == 1)
+
+
+def test_api_semantics(pkg, golden_dir):
+    """max_iterations no-op, restart, iteration(), error codes -- PathTracer's observable behaviour."""
+    scene, w, h = _golden_scenes(golden_dir)["spheres"]
+    flat = scene.build_scene()
+    with pkg.PathTracer(max_bounces=4) as pt:
+        with pytest.raises(pkg.PtcError) as e:
+            pt.path_trace(scene.camera)
+        assert e.value.code == pkg._capi.PTC_ERR_NO_SCENE
+        pt.create_buffers((w, h), flat)
+        assert pt.iteration() == 0
+        pt.max_iterations = 2
+        for _ in range(5):
+            pt.path_trace(scene.camera)
+        assert pt.iteration() == 2                      # path_tracer.cu:391: no-op past max_iterations
+        two = pt.download("color")
+        pt.restart()
+        assert pt.iteration() == 0
+        pt.path_trace(scene.camera)
+        one = pt.download("color")                      # iteration 0 overwrites (path_tracer.cu:209-214)
+        pt.path_trace(scene.camera)
+        assert np.array_equal(pt.download("color"), two)
+        assert not np.array_equal(one, two)
+        with pytest.raises(pkg.PtcError):
+            pt.max_bounces = 1000
+            pt.path_trace(scene.camera)
+        pt.max_bounces = 4
+        with pytest.raises(pkg.PtcError):
+            pt.resize_image((1, 1))
+
+
+def test_scene_validation_and_empty_mesh(pkg):
+    s = pkg.SceneDescription()
+    s.add_material("a", pkg.DiffuseMateral((0.5, 0.5, 0.5)))
+    s.add_object(pkg.Sphere((0, 0, 0), 0.5), pkg.glmlite.translate((0, 0, -2)), "a")
+    s.camera = pkg.Camera(vfov=float(np.radians(60)))
+    flat = s.build_scene()
+    with pkg.PathTracer(max_bounces=4) as pt:
+        pt.create_buffers((32, 32), flat)       # no mesh at all: the reference panics (bvh.cpp:200); accepted here
+        pt.path_trace(s.camera)
+        c = pt.download("color")
+        assert np.isfinite(c).all() and c.std() > 0
+        bad = s.build_scene()
+        bad.object_material_indices = np.array([5], dtype=np.uint32)
+        with pytest.raises(pkg.PtcError) as e:
+            pt.create_buffers((32, 32), bad)
+        assert e.value.code == pkg._capi.PTC_ERR_INVALID
