@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X path-tracing core.
+
+Metric (BASELINE.json): Mrays/s at 1920x1080, 8 bounces, on the 1,000,000-triangle scene (config 3:
+`configs[2]`, the configuration the metric is quoted on; it fits one GPU).  One "step" = one frame =
+one sample per pixel through PathTracer::path_trace (streaming mode).  1 ray = 1 closest-hit query,
+primary rays included.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the frame is split into N contiguous row bands, one process per GPU; no data-path collective
+during tracing; the bands' radiance is gathered to rank 0 over RCCL once, at present time, inside the
+timed region.  Fixed total work -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 with the contract fields plus:
+  roofline      dominant kernel = the closest-hit (trace) kernel; achieved = algorithmic bytes of all its
+                launches in the timed region / their summed duration (HIP events on the kernel's stream).
+                Algorithmic bytes per launch = n*52 + box_tests*32 + tri_tests*48,
+                with the test counts taken from an instrumented, untimed re-run of the same frames.
+  cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU path) timed on this
+                box's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-bounces", type=int, default=8)
+    ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="resolution of the CPU-oracle sample frame")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (the GPU box's CPU share for one GPU is 16)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    W, H, MB = args.width, args.height, args.max_bounces
+    nx, nz = (int(v) for v in args.grid.split("x"))
+    scene = pkg.scenes.heightfield_scene((W, H), nx=nx, nz=nz)
+    flat = scene.build_scene()
+    mesh = list(scene.mesh_map_.values())[0]
+    t0 = time.perf_counter()
+    flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)
+    bvh_build_s = time.perf_counter() - t0
+
+    # contiguous row bands
+    rows = [(H * r) // world for r in range(world + 1)]
+    row0, row1 = rows[rank], rows[rank + 1]
+
+    pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+    pt.create_buffers((W, H), flat)
+    pt.set_stream(torch.cuda.current_stream().cuda_stream)
+    if world > 1:
+        pt.set_rows(row0, row1)
+    pt.max_iterations = 1 << 30
+    band_pixels = (row1 - row0) * W
+    band_color = torch.empty((band_pixels, 3), dtype=torch.float32, device="cuda")
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty(((rows[r + 1] - rows[r]) * W, 3), dtype=torch.float32, device="cuda") for r in range(world)]
+
+    def present():
+        """gather of per-band radiance at present time (the only inter-GPU traffic)"""
+        pt.download_to_device("color", band_color.data_ptr())
+        if world > 1:
+            dist.gather(band_color, gathered if rank == 0 else None, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pt.path_trace(scene.camera)
+    present()
+    fence()
+    pt.reset_profile()
+    pt.set_profiling(time_trace_kernel=True, count_tests=False)
+    rays0 = pt.stats()["rays_total"]
+    first_iter = pt.iteration()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pt.path_trace(scene.camera)
+    present()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    rays = pt.stats()["rays_total"] - rays0
+    prof = pt.profile()
+    last_live = pt.stats()["last_live"]
+
+    # max over ranks of the elapsed time, sum of rays
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays = int(r.item())
+
+    # instrumented, untimed re-run of the same frames: BVH box / triangle test counts per bounce
+    pt.set_profiling(time_trace_kernel=False, count_tests=True)
+    paths_timed = list(prof["paths"])
+    pt.reset_profile()
+    pt.set_iteration(first_iter)
+    count_steps = min(args.steps, 4)
+    for _ in range(count_steps):
+        pt.path_trace(scene.camera)
+    counted = pt.profile()
+    pt.set_profiling(False, False)
+
+    # roofline of the dominant kernel (trace): algorithmic bytes / summed launch duration
+    scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
+    alg_bytes = sum(paths_timed[b] * 52 + scale[b] * (counted["box_tests"][b] * 32 + counted["tri_tests"][b] * 48)
+                    for b in range(MB))
+    trace_ms = sum(prof["trace_ms"])
+    launches = sum(prof["trace_launches"])
+    achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("trace_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "launches": launches, "avg_launch_us": round(trace_ms * 1e3 / max(launches, 1), 2),
+        "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
+        "trace_share_of_step": round(trace_ms * 1e-3 / elapsed, 4),
+        "box_tests_per_ray": round(sum(counted["box_tests"]) / max(sum(counted["paths"]), 1), 2),
+        "tri_tests_per_ray": round(sum(counted["tri_tests"]) / max(sum(counted["paths"]), 1), 2),
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        orc = graft.load_oracle()
+        cw, ch = (int(v) for v in args.cpu_sample.split("x"))
+        sh = orc.SceneHandle(flat)
+        cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
+        t0 = time.perf_counter()
+        ref = orc.render_streaming(flat, scene.camera, cw, ch, 0, 1, MB, nthreads=cores, scene_handle=sh)
+        dt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(ref["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                        "sample": f"1 frame of the same scene (same {len(flat.indices) // 3}-triangle BVH, {MB} bounces) at "
+                                  f"{cw}x{ch}: {ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so (CPU restatement; "
+                                  "the reference has no CPU path)"}
+
+    if rank == 0:
+        value = rays / elapsed / 1e6
+        line = {
+            "metric": "Mrays/s at 1920x1080, 8 bounces", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config 3: procedural {len(flat.indices) // 3}-triangle heightfield + 3 spheres, "
+                                   f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
+                       "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
+                       "resolution": [W, H], "max_bounces": MB, "rays_per_step": round(rays / args.steps),
+                       "live_per_bounce_last_frame_rank0": last_live, "partition": f"{world} row band(s)",
+                       "bvh_build_s": round(bvh_build_s, 3)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    pt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,12 @@ class ptc_stats(C.Structure):
                 ("stack_capacity", C.c_uint32)]
 
 
+class ptc_profile(C.Structure):
+    _fields_ = [("paths", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("box_tests", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
+                ("tri_tests", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("trace_ms", C.c_double * PTC_MAX_BOUNCES_CAP),
+                ("trace_launches", C.c_uint32 * PTC_MAX_BOUNCES_CAP)]
+
+
 # every symbol include/ptcore.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -103,6 +109,9 @@ SIGNATURES = {
     "ptc_download": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "ptc_synchronize": (C.c_int, [_P]),
     "ptc_get_stats": (C.c_int, [_P, C.POINTER(ptc_stats)]),
+    "ptc_set_profiling": (C.c_int, [_P, C.c_int, C.c_int]),
+    "ptc_reset_profile": (C.c_int, [_P]),
+    "ptc_get_profile": (C.c_int, [_P, C.POINTER(ptc_profile)]),
     "ptc_intersect_rays": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
     "ptc_build_bvh": (C.c_int, [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,

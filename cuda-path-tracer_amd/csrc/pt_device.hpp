@@ -88,6 +88,9 @@ struct DeviceCounters {
   uint32_t flags;
   uint32_t pad;
   unsigned long long rays_total;
+  unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
+  unsigned long long box_tests[kMaxBounces];  // instrumented runs only
+  unsigned long long tri_tests[kMaxBounces];
 };
 
 struct DDenoise {
@@ -98,7 +101,7 @@ struct DDenoise {
 void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters);
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
-                  uint32_t* chunk_counts, DeviceCounters* counters);
+                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

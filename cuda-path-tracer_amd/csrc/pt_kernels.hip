@@ -45,6 +45,11 @@ struct Ray {
 };
 __device__ __forceinline__ f3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }
 
+// per-lane test counters of the instrumented kernel variant
+struct Tally {
+  uint32_t boxes = 0u, tris = 0u;
+};
+
 struct Hit {
   float t;
   f3 p;
@@ -129,8 +134,9 @@ __device__ __forceinline__ void inverse_transform_ray(const m4& inv_m, const Ray
 // ray_mesh_intersection_test, path_tracer.cu:36-76.  Depth-first, left child first, every inner box
 // the line crosses is entered (the reference has no t culling).  The stack lives in LDS, laid out
 // [depth][lane] so that a push or pop of the whole wavefront touches 64 consecutive banks.
+template <bool kCount>
 __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObject* obj, Hit& rec, uint32_t* stack,
-                                         uint32_t& flags)
+                                         uint32_t& flags, Tally& tally)
 {
   bool hit = false;
   f3 oo, od;
@@ -152,11 +158,12 @@ __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObjec
       const f3 p0 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i0));
       const f3 p1 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i1));
       const f3 p2 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i2));
+      if (kCount) ++tally.tris;
       if (ray_triangle(ray, p0, p1, p2, rec)) {
         hit = true;
         ray.tmax = rec.t;
       }
-    } else if (ray_aabb(oo, od, xyz(n0), xyz(n1))) {
+    } else if ((kCount ? (void)++tally.boxes : (void)0), ray_aabb(oo, od, xyz(n0), xyz(n1))) {
       if (sp + 2 > kStackDepth) {
         flags |= kFlagStackOverflow;
       } else {
@@ -170,7 +177,9 @@ __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObjec
 }
 
 // ray_scene_intersection_test + ray_object_intersection_test, path_tracer.cu:78-128
-__device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, uint32_t* stack, uint32_t& flags)
+template <bool kCount>
+__device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, uint32_t* stack, uint32_t& flags,
+                                          Tally& tally)
 {
   bool hit = false;
   for (uint32_t i = 0; i < sc.object_count; ++i) {
@@ -190,7 +199,7 @@ __device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, u
         rec.n = xform_normal(obj->inv_m, rec.n);
       }
     } else {
-      h = ray_mesh(ray, sc, obj, rec, stack, flags);
+      h = ray_mesh<kCount>(ray, sc, obj, rec, stack, flags, tally);
     }
     if (h) {
       hit = true;
@@ -343,6 +352,7 @@ __device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
 
 // intersection_kernel, path_tracer.cu:271-290.  One wavefront per 64-path chunk; also produces the
 // chunk's live count for the compaction scan.
+template <bool kCount>
 __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits hits, int bounce, uint32_t* chunk_counts,
                                                  DeviceCounters* counters)
 {
@@ -352,6 +362,7 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
   if (blockIdx.x * kWave >= n) return;
   bool hit = false;
   uint32_t flags = 0u;
+  Tally tally;
   if (s < n) {
     const Ray ray = load_ray(paths, s);
     Hit rec;
@@ -359,13 +370,25 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
     rec.p = rec.n = mk3(0.f, 0.f, 0.f);
     rec.mat = 0u;
     rec.side = 0u;
-    hit = ray_scene(ray, sc, rec, s_stack + threadIdx.x, flags);
+    hit = ray_scene<kCount>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
     hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
     hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
     if (flags) atomicOr(&counters->flags, flags);
   }
   const uint64_t live = __ballot(hit);
   if (threadIdx.x == 0u) chunk_counts[blockIdx.x] = (uint32_t)__popcll(live);
+  if (kCount) {
+    uint32_t b = tally.boxes, t = tally.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off, 64);
+      t += __shfl_down(t, off, 64);
+    }
+    if (threadIdx.x == 0u) {
+      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
+      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+    }
+  }
 }
 
 // Exclusive scan of the per-chunk live counts (one workgroup; <= ~32k chunks at 1080p).
@@ -403,6 +426,7 @@ __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, cons
   if (threadIdx.x == 0u) {
     counters->live[bounce + 1] = last_bounce ? 0u : s_carry;
     counters->rays_total += n;
+    counters->paths[bounce] += n;
   }
 }
 
@@ -498,7 +522,8 @@ __global__ __launch_bounds__(kWave) void k_megakernel(DScene sc, DCamera cam, ui
       rec.mat = 0u;
       rec.side = 0u;
       ++rays;
-      if (!ray_scene(ray, sc, rec, s_stack + threadIdx.x, flags)) {
+      Tally tally;
+      if (!ray_scene<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally)) {
         color = color * background(ray.d);
         break;
       }
@@ -540,7 +565,8 @@ __global__ __launch_bounds__(kWave) void k_intersect(DScene sc, const float4* ra
   rec.mat = 0u;
   rec.side = 0u;
   uint32_t flags = 0u;
-  const bool hit = ray_scene(ray, sc, rec, s_stack + threadIdx.x, flags);
+  Tally tally;
+  const bool hit = ray_scene<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
   hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
   hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
   if (flags) atomicOr(&counters->flags, flags);
@@ -661,10 +687,14 @@ void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32
                      paths, counters);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
-                  uint32_t* chunk_counts, DeviceCounters* counters)
+                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests)
 {
-  hipLaunchKernelGGL(k_trace, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
-                     chunk_counts, counters);
+  if (count_tests)
+    hipLaunchKernelGGL(k_trace<true>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
+                       chunk_counts, counters);
+  else
+    hipLaunchKernelGGL(k_trace<false>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
+                       chunk_counts, counters);
 }
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters)

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -69,6 +70,18 @@ struct ptc_ctx {
   bool have_cam = false;
   bool in_frame = false;
   uint64_t frames = 0;
+
+  // measurement
+  bool time_trace = false;
+  bool count_tests = false;
+  struct TimedLaunch {
+    hipEvent_t start, stop;
+    int bounce;
+  };
+  std::vector<TimedLaunch> timed;        // recorded, not yet read
+  std::vector<hipEvent_t> free_events;
+  double trace_ms[kMaxBounces] = {};
+  uint32_t trace_launches[kMaxBounces] = {};
 };
 
 namespace {
@@ -264,6 +277,11 @@ void ptc_destroy(ptc_ctx* ctx)
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   free_pool(ctx->scene_allocs);
   free_pool(ctx->frame_allocs);
+  for (auto& tl : ctx->timed) {
+    (void)hipEventDestroy(tl.start);
+    (void)hipEventDestroy(tl.stop);
+  }
+  for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   if (ctx->counters) (void)hipFree(ctx->counters);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -464,7 +482,24 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   if (bounce < 0 || bounce >= ctx->max_bounces) return fail(ctx, PTC_ERR_INVALID, "bounce out of range");
   const bool last = bounce == ctx->max_bounces - 1;
   DPaths in = ctx->paths[ctx->cur], out = ctx->paths[ctx->cur ^ 1];
-  launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters);
+  ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
+  if (ctx->time_trace) {
+    for (hipEvent_t* e : {&tl.start, &tl.stop}) {
+      if (!ctx->free_events.empty()) {
+        *e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+      } else {
+        HIP_TRY(ctx, hipEventCreate(e));
+      }
+    }
+    HIP_TRY(ctx, hipEventRecord(tl.start, ctx->stream));
+  }
+  launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters,
+               ctx->count_tests);
+  if (ctx->time_trace) {
+    HIP_TRY(ctx, hipEventRecord(tl.stop, ctx->stream));
+    ctx->timed.push_back(tl);
+  }
   launch_scan(ctx->stream, bounce, last, ctx->chunk_counts, ctx->chunk_offsets, ctx->counters);
   launch_shade(ctx->stream, ctx->scene, in, out, ctx->hits, ctx->pix_count, (uint32_t)ctx->iteration, bounce, last,
                slot_base_dev, ctx->chunk_offsets, ctx->fb, ctx->pix_begin, ctx->counters);
@@ -610,6 +645,62 @@ int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
   out->triangle_count = ctx->triangles;
   out->stack_capacity = kStackDepth;
   if (host.flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow during rendering");
+  return PTC_OK;
+}
+
+static int drain_timed(ptc_ctx* ctx)
+{
+  for (auto& tl : ctx->timed) {
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventSynchronize(tl.stop));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, tl.start, tl.stop));
+    ctx->trace_ms[tl.bounce] += ms;
+    ctx->trace_launches[tl.bounce] += 1u;
+    ctx->free_events.push_back(tl.start);
+    ctx->free_events.push_back(tl.stop);
+  }
+  ctx->timed.clear();
+  return PTC_OK;
+}
+
+int ptc_set_profiling(ptc_ctx* ctx, int time_trace_kernel, int count_tests)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  ctx->time_trace = time_trace_kernel != 0;
+  ctx->count_tests = count_tests != 0;
+  return PTC_OK;
+}
+
+int ptc_reset_profile(ptc_ctx* ctx)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = drain_timed(ctx)) return rc;
+  std::memset(ctx->trace_ms, 0, sizeof ctx->trace_ms);
+  std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
+  const size_t off = offsetof(DeviceCounters, paths);
+  HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->counters) + off, 0, sizeof(DeviceCounters) - off, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PTC_OK;
+}
+
+int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
+{
+  if (!ctx || !out) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  DeviceCounters host;
+  HIP_TRY(ctx, hipMemcpyAsync(&host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = drain_timed(ctx)) return rc;
+  std::memset(out, 0, sizeof *out);
+  for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {
+    out->paths[b] = host.paths[b];
+    out->box_tests[b] = host.box_tests[b];
+    out->tri_tests[b] = host.tri_tests[b];
+    out->trace_ms[b] = ctx->trace_ms[b];
+    out->trace_launches[b] = ctx->trace_launches[b];
+  }
   return PTC_OK;
 }
 

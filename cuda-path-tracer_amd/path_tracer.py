@@ -173,6 +173,20 @@ class PathTracer:
                 "bvh_node_count": int(s.bvh_node_count), "bvh_max_depth": int(s.bvh_max_depth),
                 "triangle_count": int(s.triangle_count), "stack_capacity": int(s.stack_capacity)}
 
+    def set_profiling(self, time_trace_kernel=False, count_tests=False):
+        self._check(self._lib.ptc_set_profiling(self._ctx, int(time_trace_kernel), int(count_tests)))
+
+    def reset_profile(self):
+        self._check(self._lib.ptc_reset_profile(self._ctx))
+
+    def profile(self):
+        p = _capi.ptc_profile()
+        self._check(self._lib.ptc_get_profile(self._ctx, C.byref(p)))
+        n = self.max_bounces
+        return {"paths": [int(x) for x in p.paths[:n]], "box_tests": [int(x) for x in p.box_tests[:n]],
+                "tri_tests": [int(x) for x in p.tri_tests[:n]], "trace_ms": [float(x) for x in p.trace_ms[:n]],
+                "trace_launches": [int(x) for x in p.trace_launches[:n]]}
+
     def intersect_rays(self, rays):
         """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

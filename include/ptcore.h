@@ -129,6 +129,21 @@ typedef struct ptc_stats {
   uint32_t stack_capacity;                   /* traversal stack entries available per ray */
 } ptc_stats;
 
+/* Measurement support (no reference equivalent; the reference only has a wall-clock Stopwatch, cli.cpp:27-60).
+ * Per bounce index, summed over every streaming frame traced since ptc_reset_profile:
+ *   paths      live paths that entered the bounce (= closest-hit queries = rays)
+ *   trace_ms   duration of the closest-hit kernel, from HIP events recorded on the context's stream
+ *              around each launch (only while events are enabled)
+ *   box_tests  ray/AABB tests of BVH nodes, tri_tests  ray/triangle tests (only while counting is
+ *              enabled: an instrumented, slower kernel variant -- never time it) */
+typedef struct ptc_profile {
+  uint64_t paths[PTC_MAX_BOUNCES_CAP];
+  uint64_t box_tests[PTC_MAX_BOUNCES_CAP];
+  uint64_t tri_tests[PTC_MAX_BOUNCES_CAP];
+  double trace_ms[PTC_MAX_BOUNCES_CAP];
+  uint32_t trace_launches[PTC_MAX_BOUNCES_CAP];
+} ptc_profile;
+
 typedef struct ptc_ctx ptc_ctx;
 
 /* ---- lifetime ---- */
@@ -195,6 +210,9 @@ int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device);
 
 int ptc_synchronize(ptc_ctx* ctx);                                  /* cudaDeviceSynchronize at cli.cpp:100 */
 int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out);                    /* synchronises */
+int ptc_set_profiling(ptc_ctx* ctx, int time_trace_kernel, int count_tests);
+int ptc_reset_profile(ptc_ctx* ctx);
+int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out);                /* synchronises */
 
 /* ---- pieces exposed for parity tests and for host-side callers ---- */
 /* intersection_kernel alone (path_tracer.cu:271-290) on caller-supplied rays (host arrays of
