@@ -98,6 +98,7 @@ SIGNATURES = {
     "ptc_set_max_iterations": (C.c_int, [_P, C.c_int]),
     "ptc_set_method": (C.c_int, [_P, C.c_int]),
     "ptc_set_max_bounces": (C.c_int, [_P, C.c_int]),
+    "ptc_set_trace_variant": (C.c_int, [_P, C.c_int]),
     "ptc_set_denoiser_params": (C.c_int, [_P, C.POINTER(ptc_denoiser_params)]),
     "ptc_trace": (C.c_int, [_P, C.POINTER(ptc_camera)]),
     "ptc_trace_begin": (C.c_int, [_P, C.POINTER(ptc_camera)]),

@@ -36,6 +36,17 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 
 // Read-only scene in HBM.
 //   bvh: two float4 per node: {min.xyz, bits(first_child_or_primitive)}, {max.xyz, bits(primitive_count)}
+//   wide: the same tree re-laid for the fast traversal (k_trace_wide): one 64-byte record per INNER node
+//         holding both children's boxes,
+//           w0 = {lmin.xyz, lmax.x}  w1 = {lmax.yz, rmin.xy}  w2 = {rmin.z, rmax.xyz}  w3 = {bits lref, bits rref, -, -}
+//         ref = index of the child's record, or kLeafBit | rank of the child's triangle in depth-first
+//         (left-first) leaf order -- the order in which the reference's traversal reaches the leaves.
+//   tris: per MESH OBJECT (instance), world-space triangles in that depth-first order, three float4 each:
+//           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, n.xyz}   with p = transform_point(M, position),
+//           e1 = p1 - p0, e2 = p2 - p0, n = normalize(cross(e1, e2))   (exactly what the reference
+//           recomputes per test, path_tracer.cu:57-59, intersections.cuh:45-46,54-55)
+constexpr uint32_t kLeafBit = 0x80000000u;
+
 struct DScene {
   const DObject* objects;
   const uint32_t* object_material;
@@ -44,6 +55,12 @@ struct DScene {
   const float* positions;
   const uint32_t* indices;
   const float4* bvh;
+  const float4* wide;              // 4 float4 per inner node
+  const float4* tris;              // 3 float4 per instance triangle
+  const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
+  float root_min[3];               // box of the root (tested before descending, like any inner node)
+  float root_max[3];
+  uint32_t root_ref;               // record 0, or kLeafBit for a single-triangle mesh
   uint32_t object_count;
   uint32_t bvh_node_count;
 };
@@ -100,8 +117,9 @@ struct DDenoise {
 // ---- launch interface (implemented in pt_kernels.hip) ----
 void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters);
+// variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
-                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests);
+                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests, int variant);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
@@ -114,7 +132,7 @@ void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which
 void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_begin, uint32_t pix_count, const float4* color,
                          const float4* nd, float4* out, int step_width, DDenoise params);
 void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
-                      DHits hits, DeviceCounters* counters);
+                      DHits hits, DeviceCounters* counters, int variant);
 void launch_selftest(hipStream_t s, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,
                      float* out_sin, float* out_cos);
 

@@ -4,6 +4,8 @@
 #include "../../include/ptcore.h"
 #include "pt_math.hpp"
 
+#include <vector>
+
 namespace pt {
 
 // bvh_from_mesh (reference accelerators/bvh.cpp:211-253); returns node count or a negative ptc_status
@@ -19,5 +21,19 @@ m4 camera_matrix(const float position[3], const float rotation_wxyz[4]);
 // Per-object part of SceneDescription::build_scene (reference scene_description.cpp:17-52)
 int make_object(uint32_t type, uint32_t index, const float* m16, const ptc_sphere* sphere, const float* mesh_aabb6,
                 ptc_object* out);
+
+// The reference tree re-laid for the fast traversal (see DScene in pt_device.hpp).
+struct WideAccel {
+  std::vector<float4> wide;         // 4 per inner node, breadth-first order of the inner nodes
+  std::vector<uint32_t> tri_order;  // depth-first leaf rank -> triangle number (index offset / 3)
+  uint32_t root_ref = 0;
+  float root_min[3] = {0, 0, 0};
+  float root_max[3] = {0, 0, 0};
+};
+int build_wide(const ptc_bvh_node* nodes, uint32_t count, WideAccel& out);
+
+// World-space triangles of one instance in depth-first leaf order: 3 float4 per triangle.
+void build_instance_triangles(const m4& m, const float* positions, const uint32_t* indices,
+                              const std::vector<uint32_t>& tri_order, float4* out);
 
 }  // namespace pt

@@ -211,6 +211,219 @@ __device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, u
 }
 
 // ------------------------------------------------------------------------------------------------
+// fast closest hit: same result as ray_mesh / ray_scene above, different schedule
+// ------------------------------------------------------------------------------------------------
+// What the reference computes for one mesh object (path_tracer.cu:36-76) is, independent of visiting order:
+// among the triangles whose inner ancestors ALL pass ray_aabb (exact divisions, object-space ray), the one
+// with the smallest accepted t; equal t -> the one the depth-first, left-first order reaches last.
+// This traversal keeps exactly that result and changes only the schedule:
+//   * box decisions are first evaluated with one reciprocal per axis; when the two slab extremes are closer
+//     than the rounding error of that shortcut (or anything is non-finite) the exact, division-based test
+//     of the reference decides, so every inner-box decision equals the reference's;
+//   * triangles are stored in depth-first leaf order, so "reached last" = larger index (tie rule);
+//   * subtrees are skipped only when their box lies, with a safety margin, beyond the closest hit found
+//     so far or behind the ray origin (such triangles cannot be accepted), and leaves whose own box is
+//     missed with a margin are skipped (the reference tests no leaf boxes; those tests would fail);
+//   * children are visited nearest first; one LDS stack slot per level.
+constexpr int kWideStack = 32;
+
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < __builtin_inff(); }
+
+__device__ __forceinline__ void slab_fast(const f3 bmin, const f3 bmax, const f3 oo, const f3 inv, float& t_near,
+                                          float& t_far)
+{
+  const float ax = (bmin.x - oo.x) * inv.x, bx = (bmax.x - oo.x) * inv.x;
+  const float ay = (bmin.y - oo.y) * inv.y, by = (bmax.y - oo.y) * inv.y;
+  const float az = (bmin.z - oo.z) * inv.z, bz = (bmax.z - oo.z) * inv.z;
+  t_near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  t_far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+
+// the reference's test (ray_aabb) that also hands back its two extremes
+__device__ __forceinline__ bool slab_exact(const f3 bmin, const f3 bmax, const f3 o, const f3 d, float& t_near,
+                                           float& t_far)
+{
+  const f3 t0 = (bmin - o) / d;
+  const f3 t1 = (bmax - o) / d;
+  const f3 rmin = min3(t0, t1);
+  const f3 rmax = max3(t0, t1);
+  t_far = sel_min(sel_min(rmax.x, rmax.y), rmax.z);
+  t_near = sel_max(sel_max(rmin.x, rmin.y), rmin.z);
+  return t_far >= t_near;
+}
+
+// Decision of an INNER node's box, equal to the reference's.  The shortcut's extremes differ from the exact
+// ones by at most ~3 ulp each (one rounding of 1/d, one of the product, against one of the quotient).
+__device__ __forceinline__ bool box_pass_inner(const f3 bmin, const f3 bmax, const f3 oo, const f3 od, const f3 inv,
+                                               const bool exact_only, float& t_near, float& t_far)
+{
+  if (!exact_only) {
+    slab_fast(bmin, bmax, oo, inv, t_near, t_far);
+    const float gap = t_far - t_near;
+    const float tol = 4e-7f * (fabsf(t_far) + fabsf(t_near)) + 1e-30f;
+    if (gap > tol) return true;
+    if (gap < -tol) return false;
+  }
+  return slab_exact(bmin, bmax, oo, od, t_near, t_far);
+}
+
+// May this child be skipped although its box test passed?  limit = |M^-1 d| * (closest t so far): the same
+// distance measured along the object-space ray.  NaN compares false -> never skipped.
+__device__ __forceinline__ bool box_culled(const float t_near, const float t_far, const float limit)
+{
+  return (t_near > limit * 1.001f + 1e-3f * (t_far - t_near)) || (t_far < -1e-3f * fabsf(t_near));
+}
+
+template <bool kCount>
+__device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& sc, const DObject* obj,
+                                                  const uint32_t tri_base, float& best_t, int& best_k, uint32_t* stack,
+                                                  uint32_t& flags, Tally& tally)
+{
+  if (sc.bvh_node_count == 0u) return;
+  // inverse_transform_ray (transform.hpp:51-58); scale = length before the re-normalisation
+  const f3 v = xform_vector(obj->inv_m, ray.d);
+  const float scale = ieee_sqrt(dot(v, v));
+  const f3 od = v * (1.0f / scale);
+  const f3 oo = xform_point(obj->inv_m, ray.o);
+  const f3 inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+  const bool exact_only = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z));
+  float limit = scale * best_t;
+
+  uint32_t cur = sc.root_ref;
+  if (!(cur & kLeafBit)) {
+    float tn, tf;
+    if (kCount) ++tally.boxes;
+    if (!box_pass_inner(ld3(sc.root_min), ld3(sc.root_max), oo, od, inv, exact_only, tn, tf)) return;
+    if (box_culled(tn, tf, limit)) return;
+  }
+  const float4* tris = sc.tris + 3u * (size_t)tri_base;
+  int sp = 0;
+  for (;;) {
+    if (cur & kLeafBit) {
+      // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
+      const uint32_t k = cur & ~kLeafBit;
+      const float4 ta = tris[3u * k], tb = tris[3u * k + 1u], tc = tris[3u * k + 2u];
+      if (kCount) ++tally.tris;
+      const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
+      const f3 h = cross(ray.d, e2);
+      const float a = dot(e1, h);
+      if (!(a > -0.0000001f && a < 0.0000001f)) {
+        const float f = 1.0f / a;
+        const f3 sv = ray.o - p0;
+        const float u = f * dot(sv, h);
+        if (!(u < 0.0f || u > 1.0f)) {
+          const f3 q = cross(sv, e1);
+          const float w = f * dot(ray.d, q);
+          if (!(w < 0.0f || u + w > 1.0f)) {
+            const float t = f * dot(e2, q);
+            if (!(t < ray.tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
+              best_t = t;
+              best_k = (int)k;
+              limit = scale * t;
+            }
+          }
+        }
+      }
+      if (sp == 0) break;
+      --sp;
+      cur = stack[sp * kWave];
+      continue;
+    }
+    const float4 w0 = sc.wide[4u * (size_t)cur], w1 = sc.wide[4u * (size_t)cur + 1u];
+    const float4 w2 = sc.wide[4u * (size_t)cur + 2u], w3 = sc.wide[4u * (size_t)cur + 3u];
+    const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
+    const f3 lmin = mk3(w0.x, w0.y, w0.z), lmax = mk3(w0.w, w1.x, w1.y);
+    const f3 rmin = mk3(w1.z, w1.w, w2.x), rmax = mk3(w2.y, w2.z, w2.w);
+    if (kCount) tally.boxes += 2u;
+    float ln, lf, rn, rf;
+    bool go_l, go_r;
+    if (lref & kLeafBit) {
+      // leaf boxes are not part of the reference's decision; skip the triangle only when its box is
+      // missed with a margin far larger than any rounding
+      slab_fast(lmin, lmax, oo, inv, ln, lf);
+      go_l = exact_only || !((lf - ln) < -(1e-4f * (fabsf(lf) + fabsf(ln)) + 1e-30f));
+    } else {
+      go_l = box_pass_inner(lmin, lmax, oo, od, inv, exact_only, ln, lf);
+    }
+    if (rref & kLeafBit) {
+      slab_fast(rmin, rmax, oo, inv, rn, rf);
+      go_r = exact_only || !((rf - rn) < -(1e-4f * (fabsf(rf) + fabsf(rn)) + 1e-30f));
+    } else {
+      go_r = box_pass_inner(rmin, rmax, oo, od, inv, exact_only, rn, rf);
+    }
+    go_l = go_l && !box_culled(ln, lf, limit);
+    go_r = go_r && !box_culled(rn, rf, limit);
+    if (go_l && go_r) {
+      const bool left_first = !(rn < ln);
+      const uint32_t first = left_first ? lref : rref, second = left_first ? rref : lref;
+      if (sp >= kWideStack) {
+        flags |= kFlagStackOverflow;
+      } else {
+        stack[sp * kWave] = second;
+        ++sp;
+      }
+      cur = first;
+    } else if (go_l || go_r) {
+      cur = go_l ? lref : rref;
+    } else {
+      if (sp == 0) break;
+      --sp;
+      cur = stack[sp * kWave];
+    }
+  }
+}
+
+// ray_scene_intersection_test with the fast mesh traversal.  Spheres and the per-object world-box test
+// are the reference's code; a mesh winner's normal / side / point are filled in once at the end.
+template <bool kCount>
+__device__ __forceinline__ bool ray_scene_wide(Ray ray, const DScene& sc, Hit& rec, uint32_t* stack, uint32_t& flags,
+                                               Tally& tally)
+{
+  bool hit = false;
+  int win_tri = -1;
+  for (uint32_t i = 0; i < sc.object_count; ++i) {
+    const DObject* obj = sc.objects + i;
+    if (!ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax))) continue;
+    if (obj->type == 0u) {
+      Ray tr;
+      inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
+      tr.tmin = ray.tmin;
+      tr.tmax = ray.tmax;
+      const float4 sp = sc.spheres[obj->index];
+      if (ray_sphere(tr, xyz(sp), sp.w, rec)) {
+        rec.p = xform_point(obj->m, rec.p);
+        rec.t = length(rec.p - ray.o);
+        rec.n = xform_normal(obj->inv_m, rec.n);
+        rec.mat = sc.object_material[i];
+        ray.tmax = rec.t;
+        hit = true;
+        win_tri = -1;
+      }
+    } else {
+      float t = ray.tmax;
+      int k = -1;
+      const uint32_t base = sc.object_tri_base[i];
+      mesh_closest_wide<kCount>(ray, sc, obj, base, t, k, stack, flags, tally);
+      if (k >= 0) {
+        ray.tmax = t;
+        rec.t = t;
+        rec.mat = sc.object_material[i];
+        hit = true;
+        win_tri = (int)(base + (uint32_t)k);
+      }
+    }
+  }
+  if (win_tri >= 0) {
+    const float4 tc = sc.tris[3u * (size_t)win_tri + 2u];
+    const f3 outward = mk3(tc.y, tc.z, tc.w);
+    rec.p = ray_at(ray, rec.t);
+    rec.side = dot(ray.d, outward) < 0.0f ? 0u : 1u;
+    rec.n = rec.side == 0u ? outward : -outward;
+  }
+  return hit;
+}
+
+// ------------------------------------------------------------------------------------------------
 // shading (path_tracer.cu:29-34, 130-201; distributions.cuh:6-19)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f3 background(const f3 dir)
@@ -391,6 +604,52 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
   }
 }
 
+// The same kernel over the wide layout (default).  Chunks are dealt to workgroups so that workgroups that
+// share an XCD (blockIdx % 8, MI355X_MICROARCH.md "Workgroup dispatch") get one contiguous run of
+// chunks = one contiguous image region: neighbouring paths walk the same subtrees, which keeps that
+// XCD's 4 MiB L2 on one part of the BVH.  Placement only affects speed.
+template <bool kCount>
+__global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, DHits hits, int bounce,
+                                                      uint32_t* chunk_counts, DeviceCounters* counters)
+{
+  __shared__ uint32_t s_stack[kWideStack * kWave];
+  const uint32_t n = counters->live[bounce];
+  const uint32_t chunks = (n + kChunk - 1u) / kChunk;
+  const uint32_t per_xcd = (chunks + 7u) / 8u;
+  const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || chunk >= chunks) return;
+  const uint32_t s = chunk * kWave + threadIdx.x;
+  bool hit = false;
+  uint32_t flags = 0u;
+  Tally tally;
+  if (s < n) {
+    const Ray ray = load_ray(paths, s);
+    Hit rec;
+    rec.t = 0.0f;
+    rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+    rec.mat = 0u;
+    rec.side = 0u;
+    hit = ray_scene_wide<kCount>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
+    hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
+    hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+    if (flags) atomicOr(&counters->flags, flags);
+  }
+  const uint64_t live = __ballot(hit);
+  if (threadIdx.x == 0u) chunk_counts[chunk] = (uint32_t)__popcll(live);
+  if (kCount) {
+    uint32_t b = tally.boxes, t = tally.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off, 64);
+      t += __shfl_down(t, off, 64);
+    }
+    if (threadIdx.x == 0u) {
+      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
+      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+    }
+  }
+}
+
 // Exclusive scan of the per-chunk live counts (one workgroup; <= ~32k chunks at 1080p).
 // Writes live[bounce+1] (0 after the last bounce: nothing survives the cap) and the ray counter.
 __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, const uint32_t* chunk_counts,
@@ -547,6 +806,7 @@ __global__ __launch_bounds__(kWave) void k_megakernel(DScene sc, DCamera cam, ui
 }
 
 // intersection_kernel on caller-supplied rays (parity tests): rays_o = origin.xyz,t_min ; rays_d = direction.xyz,t_max
+template <int kVariant>
 __global__ __launch_bounds__(kWave) void k_intersect(DScene sc, const float4* rays_o, const float4* rays_d, uint32_t n,
                                                      DHits hits, DeviceCounters* counters)
 {
@@ -566,7 +826,8 @@ __global__ __launch_bounds__(kWave) void k_intersect(DScene sc, const float4* ra
   rec.side = 0u;
   uint32_t flags = 0u;
   Tally tally;
-  const bool hit = ray_scene<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
+  const bool hit = kVariant == 0 ? ray_scene<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally)
+                                 : ray_scene_wide<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
   hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
   hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
   if (flags) atomicOr(&counters->flags, flags);
@@ -687,8 +948,16 @@ void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32
                      paths, counters);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
-                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests)
+                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests, int variant)
 {
+  if (variant == 1) {
+    const dim3 grid(div_up(max_paths, kWave) + 8u);  // room for the per-XCD rounding of the chunk deal
+    if (count_tests)
+      hipLaunchKernelGGL(k_trace_wide<true>, grid, dim3(kWave), 0, s, scene, paths, hits, bounce, chunk_counts, counters);
+    else
+      hipLaunchKernelGGL(k_trace_wide<false>, grid, dim3(kWave), 0, s, scene, paths, hits, bounce, chunk_counts, counters);
+    return;
+  }
   if (count_tests)
     hipLaunchKernelGGL(k_trace<true>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
                        chunk_counts, counters);
@@ -731,9 +1000,12 @@ void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_begin, 
                      step_width, params);
 }
 void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
-                      DHits hits, DeviceCounters* counters)
+                      DHits hits, DeviceCounters* counters, int variant)
 {
-  hipLaunchKernelGGL(k_intersect, dim3(div_up(n, kWave)), dim3(kWave), 0, s, scene, rays_o, rays_d, n, hits, counters);
+  if (variant == 1)
+    hipLaunchKernelGGL(k_intersect<1>, dim3(div_up(n, kWave)), dim3(kWave), 0, s, scene, rays_o, rays_d, n, hits, counters);
+  else
+    hipLaunchKernelGGL(k_intersect<0>, dim3(div_up(n, kWave)), dim3(kWave), 0, s, scene, rays_o, rays_d, n, hits, counters);
 }
 void launch_selftest(hipStream_t s, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,
                      float* out_sin, float* out_cos)

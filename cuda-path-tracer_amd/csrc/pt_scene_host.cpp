@@ -1,5 +1,6 @@
 // pt_scene_host.cpp -- host-side scene flattening helpers (no GPU).
 #include "pt_host.hpp"
+#include "pt_device.hpp"
 
 #include <cfloat>
 #include <cstring>
@@ -138,6 +139,76 @@ int make_object(uint32_t type, uint32_t index, const float* m16, const ptc_spher
   out->aabb_min[0] = lo.x; out->aabb_min[1] = lo.y; out->aabb_min[2] = lo.z;
   out->aabb_max[0] = hi.x; out->aabb_max[1] = hi.y; out->aabb_max[2] = hi.z;
   return PTC_OK;
+}
+
+int build_wide(const ptc_bvh_node* nodes, uint32_t count, WideAccel& out)
+{
+  out.wide.clear();
+  out.tri_order.clear();
+  if (count == 0) return PTC_OK;
+  // ranks: inner nodes in array (breadth-first) order, leaves in depth-first left-first order
+  std::vector<uint32_t> inner_rank(count, 0u), leaf_rank(count, 0u);
+  uint32_t inner_count = 0;
+  for (uint32_t i = 0; i < count; ++i)
+    if (nodes[i].primitive_count == 0u) inner_rank[i] = inner_count++;
+  {
+    std::vector<uint32_t> stack;
+    stack.push_back(0u);
+    while (!stack.empty()) {
+      const uint32_t i = stack.back();
+      stack.pop_back();
+      if (nodes[i].primitive_count != 0u) {
+        leaf_rank[i] = (uint32_t)out.tri_order.size();
+        out.tri_order.push_back(nodes[i].first_child_or_primitive / 3u);
+      } else {
+        stack.push_back(nodes[i].first_child_or_primitive + 1u);
+        stack.push_back(nodes[i].first_child_or_primitive);
+      }
+    }
+  }
+  auto ref_of = [&](uint32_t i) { return nodes[i].primitive_count != 0u ? (kLeafBit | leaf_rank[i]) : inner_rank[i]; };
+  auto bits = [](uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  out.wide.resize((size_t)inner_count * 4u);
+  for (uint32_t i = 0; i < count; ++i) {
+    if (nodes[i].primitive_count != 0u) continue;
+    const ptc_bvh_node& l = nodes[nodes[i].first_child_or_primitive];
+    const ptc_bvh_node& r = nodes[nodes[i].first_child_or_primitive + 1u];
+    float4* w = &out.wide[(size_t)inner_rank[i] * 4u];
+    w[0] = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
+    w[1] = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
+    w[2] = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+    w[3] = make_float4(bits(ref_of(nodes[i].first_child_or_primitive)), bits(ref_of(nodes[i].first_child_or_primitive + 1u)),
+                       0.0f, 0.0f);
+  }
+  out.root_ref = ref_of(0u);
+  for (int k = 0; k < 3; ++k) {
+    out.root_min[k] = nodes[0].aabb_min[k];
+    out.root_max[k] = nodes[0].aabb_max[k];
+  }
+  return PTC_OK;
+}
+
+void build_instance_triangles(const m4& m, const float* positions, const uint32_t* indices,
+                              const std::vector<uint32_t>& tri_order, float4* out)
+{
+  for (size_t k = 0; k < tri_order.size(); ++k) {
+    const uint32_t* idx = indices + 3u * (size_t)tri_order[k];
+    f3 p[3];
+    for (int v = 0; v < 3; ++v) {
+      const float* q = positions + 3u * (size_t)idx[v];
+      p[v] = xform_point(m, mk3(q[0], q[1], q[2]));
+    }
+    const f3 e1 = p[1] - p[0];
+    const f3 e2 = p[2] - p[0];
+    const f3 n = normalize(cross(e1, e2));
+    out[3u * k] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
+    out[3u * k + 1u] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    out[3u * k + 2u] = make_float4(e2.z, n.x, n.y, n.z);
+  }
 }
 
 }  // namespace pt

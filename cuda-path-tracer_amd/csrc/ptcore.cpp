@@ -71,6 +71,8 @@ struct ptc_ctx {
   bool in_frame = false;
   uint64_t frames = 0;
 
+  int trace_variant = 1;  // 0: reference-order traversal, 1: culled near-first traversal (default)
+
   // measurement
   bool time_trace = false;
   bool count_tests = false;
@@ -189,6 +191,8 @@ int validate_bvh(ptc_ctx* ctx, const ptc_bvh_node* nodes, uint32_t count, uint32
     } else if ((uint64_t)n.first_child_or_primitive + 1u >= count || n.first_child_or_primitive <= i) {
       return fail(ctx, PTC_ERR_INVALID, "BVH child out of range");
     }
+    for (int k = 0; k < 3; ++k)
+      if (!(n.aabb_min[k] <= n.aabb_max[k])) return fail(ctx, PTC_ERR_INVALID, "BVH node with an empty or NaN box");
   }
   return PTC_OK;
 }
@@ -349,6 +353,28 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
   }
   if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) return rc;
+
+  // layout for the fast traversal: wide inner records + per-instance world-space triangles
+  WideAccel wa;
+  if (int rc = build_wide(nodes, node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
+  std::vector<uint32_t> tri_base(s->object_count, 0u);
+  size_t mesh_objects = 0;
+  for (uint32_t i = 0; i < s->object_count; ++i)
+    if (s->objects[i].type == 1u) tri_base[i] = (uint32_t)(mesh_objects++ * wa.tri_order.size());
+  if (mesh_objects * wa.tri_order.size() > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
+  std::vector<float4> tris(mesh_objects * wa.tri_order.size() * 3u);
+  for (uint32_t i = 0; i < s->object_count; ++i) {
+    if (s->objects[i].type != 1u || wa.tri_order.empty()) continue;
+    m4 m;
+    std::memcpy(&m, s->objects[i].m, sizeof m);
+    build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * 3u);
+  }
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
+  std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
+  std::memcpy(d.root_max, wa.root_max, sizeof d.root_max);
+  d.root_ref = wa.root_ref;
   d.object_count = s->object_count;
   d.bvh_node_count = node_count;
   ctx->scene = d;
@@ -446,6 +472,13 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
   return PTC_OK;
 }
 
+int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
+{
+  if (!ctx || variant < 0 || variant > 1) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
+  ctx->trace_variant = variant;
+  return PTC_OK;
+}
+
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p)
 {
   if (!ctx || !p) return PTC_ERR_INVALID;
@@ -495,7 +528,7 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     HIP_TRY(ctx, hipEventRecord(tl.start, ctx->stream));
   }
   launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters,
-               ctx->count_tests);
+               ctx->count_tests, ctx->trace_variant);
   if (ctx->time_trace) {
     HIP_TRY(ctx, hipEventRecord(tl.stop, ctx->stream));
     ctx->timed.push_back(tl);
@@ -731,7 +764,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   hipError_t e = hipMemcpyAsync(ro, ho.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(rd, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->counters);
+    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->counters, ctx->trace_variant);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(tp.data(), hits.tp, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);

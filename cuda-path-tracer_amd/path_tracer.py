@@ -173,6 +173,9 @@ class PathTracer:
                 "bvh_node_count": int(s.bvh_node_count), "bvh_max_depth": int(s.bvh_max_depth),
                 "triangle_count": int(s.triangle_count), "stack_capacity": int(s.stack_capacity)}
 
+    def set_trace_variant(self, variant):
+        self._check(self._lib.ptc_set_trace_variant(self._ctx, int(variant)))
+
     def set_profiling(self, time_trace_kernel=False, count_tests=False):
         self._check(self._lib.ptc_set_profiling(self._ctx, int(time_trace_kernel), int(count_tests)))
 

@@ -175,6 +175,10 @@ int ptc_set_max_iterations(ptc_ctx* ctx, int max_iterations);       /* PathTrace
 int ptc_set_method(ptc_ctx* ctx, int method);                       /* PathTracer::current_gpu_method */
 int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces);             /* static max_bounces = 50, path_tracer.cu:27 */
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* PathTracer::atrous_denoiser */
+/* Closest-hit kernel variant: 1 (default) = culled, near-first traversal over the wide node layout;
+ * 0 = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no t culling).
+ * Both return the same hits (same box decisions, same tie rule); 0 exists to cross-check 1 on the GPU. */
+int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
 
 /* ---- the hot path ---- */
 /* PathTracer::path_trace (path_tracer.cu:389-477): one sample per pixel, accumulated as a running
