@@ -13,6 +13,7 @@ constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kChunk = 64;           // paths per compaction chunk = one wavefront
 constexpr int kStackDepth = 64;      // traversal stack entries per ray (LDS, [depth][lane])
 constexpr int kMaxBounces = 64;      // == PTC_MAX_BOUNCES_CAP
+constexpr int kWorkSlots = 512;      // persistent traversal launches per frame that get their own fetch cursors
 
 // error bits in DeviceCounters::flags
 constexpr uint32_t kFlagStackOverflow = 1u;
@@ -108,6 +109,8 @@ struct DeviceCounters {
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
   unsigned long long tri_tests[kMaxBounces];
+  uint32_t max_box_tests[kMaxBounces];        // longest single traversal (box tests of one ray), instrumented runs
+  uint32_t work[kWorkSlots][8];               // ray-fetch cursors of the persistent traversal launches (per image region)
 };
 
 struct DDenoise {
@@ -120,6 +123,15 @@ void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests, int variant);
+// variant 2 (default): per bounce, the objects are walked in the reference's order as a sequence of segments:
+//   launch_spheres  objects [obj_begin, obj_end), all spheres; carries the closest hit so far in the hit record
+//                   (first: nothing to read; last: also emits the per-chunk live counts for the compaction scan)
+//   launch_traverse one mesh object: persistent wavefronts, each lane fetches the next ray when its own is done
+void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
+                    DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
+                    DeviceCounters* counters);
+void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

@@ -335,21 +335,28 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
     const f3 lmin = mk3(w0.x, w0.y, w0.z), lmax = mk3(w0.w, w1.x, w1.y);
     const f3 rmin = mk3(w1.z, w1.w, w2.x), rmax = mk3(w2.y, w2.z, w2.w);
     if (kCount) tally.boxes += 2u;
+    // Both children through the same code.  An inner child's decision must equal the reference's: the
+    // shortcut decides unless the slab extremes are closer than its rounding error (then: exact test).
+    // A leaf child's box is not part of the reference's decision: its triangle is skipped only when the
+    // box is missed by a margin far beyond rounding.
     float ln, lf, rn, rf;
-    bool go_l, go_r;
-    if (lref & kLeafBit) {
-      // leaf boxes are not part of the reference's decision; skip the triangle only when its box is
-      // missed with a margin far larger than any rounding
-      slab_fast(lmin, lmax, oo, inv, ln, lf);
-      go_l = exact_only || !((lf - ln) < -(1e-4f * (fabsf(lf) + fabsf(ln)) + 1e-30f));
-    } else {
-      go_l = box_pass_inner(lmin, lmax, oo, od, inv, exact_only, ln, lf);
-    }
-    if (rref & kLeafBit) {
-      slab_fast(rmin, rmax, oo, inv, rn, rf);
-      go_r = exact_only || !((rf - rn) < -(1e-4f * (fabsf(rf) + fabsf(rn)) + 1e-30f));
-    } else {
-      go_r = box_pass_inner(rmin, rmax, oo, od, inv, exact_only, rn, rf);
+    slab_fast(lmin, lmax, oo, inv, ln, lf);
+    slab_fast(rmin, rmax, oo, inv, rn, rf);
+    const bool l_leaf = (lref & kLeafBit) != 0u, r_leaf = (rref & kLeafBit) != 0u;
+    const float lgap = lf - ln, rgap = rf - rn;
+    const float ltol = (l_leaf ? 1e-4f : 4e-7f) * (fabsf(lf) + fabsf(ln)) + 1e-30f;
+    const float rtol = (r_leaf ? 1e-4f : 4e-7f) * (fabsf(rf) + fabsf(rn)) + 1e-30f;
+    bool go_l = l_leaf ? !(lgap < -ltol) : (lgap > ltol);
+    bool go_r = r_leaf ? !(rgap < -rtol) : (rgap > rtol);
+    const bool l_unsure = !l_leaf && (exact_only || !(lgap > ltol || lgap < -ltol));
+    const bool r_unsure = !r_leaf && (exact_only || !(rgap > rtol || rgap < -rtol));
+    if (__builtin_expect(l_unsure || r_unsure || exact_only, 0)) {
+      if (l_unsure) go_l = slab_exact(lmin, lmax, oo, od, ln, lf);
+      if (r_unsure) go_r = slab_exact(rmin, rmax, oo, od, rn, rf);
+      if (exact_only) {
+        go_l = go_l || l_leaf;
+        go_r = go_r || r_leaf;
+      }
     }
     go_l = go_l && !box_culled(ln, lf, limit);
     go_r = go_r && !box_culled(rn, rf, limit);
@@ -537,6 +544,8 @@ __global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration,
   if (s == 0u) {
     counters->live[0] = pix_count;
   }
+  if (blockIdx.x == 0u)  // fetch cursors of this frame's persistent traversal launches
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0])[i] = 0u;
   if (s >= pix_count) return;
   const uint32_t pixel = pix_begin + s;
   const uint32_t x = pixel % cam.width, y = pixel / cam.width;
@@ -597,9 +606,13 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
       b += __shfl_down(b, off, 64);
       t += __shfl_down(t, off, 64);
     }
+    uint32_t mx = tally.boxes;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
     if (threadIdx.x == 0u) {
       atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
       atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+      atomicMax(&counters->max_box_tests[bounce], mx);
     }
   }
 }
@@ -643,10 +656,287 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
       b += __shfl_down(b, off, 64);
       t += __shfl_down(t, off, 64);
     }
+    uint32_t mx = tally.boxes;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
+    if (threadIdx.x == 0u) {
+      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
+      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+      atomicMax(&counters->max_box_tests[bounce], mx);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// variant 2: persistent traversal with per-lane ray fetch
+// ------------------------------------------------------------------------------------------------
+// Traversal lengths differ by an order of magnitude between neighbouring rays (a ray that grazes the
+// terrain tests hundreds of boxes, its neighbour a few dozen), so "one wavefront = 64 fixed rays" leaves
+// most lanes idle most of the time (measured: 21 % of lanes active per VALU instruction).  Here a wavefront
+// lives for the whole launch and every lane that finishes its ray takes the next unprocessed one from a
+// device-side cursor.  Results are written per slot, so the order in which rays are processed is
+// irrelevant to the output.  One launch handles ONE mesh object (its matrices stay in scalar registers);
+// the closest hit so far travels in the hit record between the segments of a bounce.
+constexpr uint32_t kRefillLanes = 20u;  // fetch new rays once this many lanes are idle
+
+template <bool kCount, bool kFirst>
+__global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
+                                                    int work_slot, DeviceCounters* counters)
+{
+  __shared__ uint32_t s_stack[kWideStack * kWave];
+  uint32_t* stack = s_stack + threadIdx.x;
+  const uint32_t n = counters->live[bounce];
+  if (n == 0u) return;
+  const DObject* obj = sc.objects + obj_index;
+  const uint32_t mat = sc.object_material[obj_index];
+  const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
+  // Eight image regions, one fetch cursor each; a wavefront starts in the region of its XCD (blockIdx % 8)
+  // and moves on when a region is used up.  Rays are reserved in batches (one atomic per batch: a single
+  // counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue") and handed to idle lanes
+  // from the wavefront's private range.
+  const uint32_t region_size = ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave;
+  const uint32_t per_wave = n / gridDim.x;
+  const uint32_t batch = per_wave >= 256u ? 256u : (per_wave >= 128u ? 128u : (uint32_t)kWave);
+  if (blockIdx.x >= (n + batch - 1u) / batch + 8u) return;  // more wavefronts than batches: nothing to do
+  uint32_t region = blockIdx.x & 7u, regions_tried = 0u;
+  uint32_t priv_next = 0u, priv_end = 0u;
+
+  bool active = false;
+  bool exact_only = false;
+  uint32_t slot = 0u, cur = 0u, flags = 0u;
+  int sp = 0, best_k = -1;
+  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), od = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
+  Tally tally;
+  uint32_t ray_boxes = 0u;
+
+  for (;;) {
+    const uint64_t idle_mask = __ballot(!active);
+    const uint32_t idle = (uint32_t)__popcll(idle_mask);
+    const bool more = priv_next < priv_end || regions_tried < 8u;
+    if (more && (idle == (uint32_t)kWave || idle >= kRefillLanes)) {
+      while (priv_next >= priv_end && regions_tried < 8u) {
+        const uint32_t region_begin = region * region_size;
+        const uint32_t region_len = region_begin < n ? min(n - region_begin, region_size) : 0u;
+        uint32_t base = region_len;
+        if (threadIdx.x == 0u && region_len != 0u &&
+            __hip_atomic_load(&counters->work[work_slot][region], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < region_len)
+          base = atomicAdd(&counters->work[work_slot][region], batch);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= region_len) {
+          region = (region + 1u) & 7u;  // used up: help with the next region
+          ++regions_tried;
+        } else {
+          priv_next = region_begin + base;
+          priv_end = region_begin + min(region_len, base + batch);
+        }
+      }
+      const uint32_t mine = priv_next + rank_below(idle_mask);
+      const uint32_t range_end = priv_end;
+      priv_next = min(priv_end, priv_next + idle);
+      if (!active && mine < range_end) {
+        slot = mine;
+        const float4 o4 = paths.o4[slot];
+        const float4 d4 = paths.d4[slot];
+        ro = xyz(o4);
+        rd = xyz(d4);
+        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
+        float t_in = FLT_MAX;
+        if (!kFirst) {
+          const float carried = hits.tp[slot].x;
+          if (carried >= 0.0f) t_in = carried;
+        }
+        bool go = sc.bvh_node_count != 0u && ray_aabb(ro, rd, ld3(obj->bmin), ld3(obj->bmax));  // path_tracer.cu:84
+        if (go) {
+          const f3 v = xform_vector(obj->inv_m, rd);  // inverse_transform_ray, transform.hpp:51-58
+          scale = ieee_sqrt(dot(v, v));
+          od = v * (1.0f / scale);
+          oo = xform_point(obj->inv_m, ro);
+          inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+          exact_only = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z));
+          best_t = t_in;
+          best_k = -1;
+          limit = scale * best_t;
+          cur = sc.root_ref;
+          sp = 0;
+          ray_boxes = 0u;
+          if (!(cur & kLeafBit)) {
+            float tn, tf;
+            if (kCount) { ++tally.boxes; ++ray_boxes; }
+            go = box_pass_inner(ld3(sc.root_min), ld3(sc.root_max), oo, od, inv, exact_only, tn, tf) &&
+                 !box_culled(tn, tf, limit);
+          }
+        }
+        if (go) active = true;
+        else if (kFirst) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (__ballot(active) == 0ull) {
+      if (priv_next >= priv_end && regions_tried >= 8u) break;
+      continue;
+    }
+
+    bool done = false;
+    if (active && !(cur & kLeafBit)) {
+      const float4 w0 = sc.wide[4u * (size_t)cur], w1 = sc.wide[4u * (size_t)cur + 1u];
+      const float4 w2 = sc.wide[4u * (size_t)cur + 2u], w3 = sc.wide[4u * (size_t)cur + 3u];
+      const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
+      const f3 lmin = mk3(w0.x, w0.y, w0.z), lmax = mk3(w0.w, w1.x, w1.y);
+      const f3 rmin = mk3(w1.z, w1.w, w2.x), rmax = mk3(w2.y, w2.z, w2.w);
+      if (kCount) { tally.boxes += 2u; ray_boxes += 2u; }
+      float ln, lf, rn, rf;
+      slab_fast(lmin, lmax, oo, inv, ln, lf);
+      slab_fast(rmin, rmax, oo, inv, rn, rf);
+      const bool l_leaf = (lref & kLeafBit) != 0u, r_leaf = (rref & kLeafBit) != 0u;
+      const float lgap = lf - ln, rgap = rf - rn;
+      const float ltol = (l_leaf ? 1e-4f : 4e-7f) * (fabsf(lf) + fabsf(ln)) + 1e-30f;
+      const float rtol = (r_leaf ? 1e-4f : 4e-7f) * (fabsf(rf) + fabsf(rn)) + 1e-30f;
+      bool go_l = l_leaf ? !(lgap < -ltol) : (lgap > ltol);
+      bool go_r = r_leaf ? !(rgap < -rtol) : (rgap > rtol);
+      const bool l_unsure = !l_leaf && (exact_only || !(lgap > ltol || lgap < -ltol));
+      const bool r_unsure = !r_leaf && (exact_only || !(rgap > rtol || rgap < -rtol));
+      if (__builtin_expect(l_unsure || r_unsure || exact_only, 0)) {
+        if (l_unsure) go_l = slab_exact(lmin, lmax, oo, od, ln, lf);
+        if (r_unsure) go_r = slab_exact(rmin, rmax, oo, od, rn, rf);
+        if (exact_only) {
+          go_l = go_l || l_leaf;
+          go_r = go_r || r_leaf;
+        }
+      }
+      go_l = go_l && !box_culled(ln, lf, limit);
+      go_r = go_r && !box_culled(rn, rf, limit);
+      if (go_l && go_r) {
+        const bool left_first = !(rn < ln);
+        if (sp >= kWideStack) {
+          flags |= kFlagStackOverflow;
+        } else {
+          stack[sp * kWave] = left_first ? rref : lref;
+          ++sp;
+        }
+        cur = left_first ? lref : rref;
+      } else if (go_l || go_r) {
+        cur = go_l ? lref : rref;
+      } else if (sp == 0) {
+        done = true;
+      } else {
+        --sp;
+        cur = stack[sp * kWave];
+      }
+    }
+    if (active && !done && (cur & kLeafBit)) {
+      const uint32_t k = cur & ~kLeafBit;
+      const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
+      if (kCount) ++tally.tris;
+      const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
+      const f3 h = cross(rd, e2);
+      const float a = dot(e1, h);
+      if (!(a > -0.0000001f && a < 0.0000001f)) {
+        const float f = 1.0f / a;
+        const f3 sv = ro - p0;
+        const float u = f * dot(sv, h);
+        if (!(u < 0.0f || u > 1.0f)) {
+          const f3 q = cross(sv, e1);
+          const float w = f * dot(rd, q);
+          if (!(w < 0.0f || u + w > 1.0f)) {
+            const float t = f * dot(e2, q);
+            if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
+              best_t = t;
+              best_k = (int)k;
+              limit = scale * t;
+            }
+          }
+        }
+      }
+      if (sp == 0) {
+        done = true;
+      } else {
+        --sp;
+        cur = stack[sp * kWave];
+      }
+    }
+    if (done) {
+      if (best_k >= 0) {
+        const float4 tc = tris[3u * (size_t)best_k + 2u];
+        const f3 outward = mk3(tc.y, tc.z, tc.w);
+        const f3 p = ro + rd * best_t;
+        const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
+        const f3 nn = side == 0u ? outward : -outward;
+        hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
+        hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+      } else if (kFirst) {
+        hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      }
+      if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
+      active = false;
+    }
+  }
+  if (flags) atomicOr(&counters->flags, flags);
+  if (kCount) {
+    uint32_t b = tally.boxes, t = tally.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off, 64);
+      t += __shfl_down(t, off, 64);
+    }
     if (threadIdx.x == 0u) {
       atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
       atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
     }
+  }
+}
+
+// Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test,
+// path_tracer.cu:78-100), continuing from / handing on the closest hit in the hit record.
+template <bool kFirst, bool kLast>
+__global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
+                                                 int bounce, uint32_t* chunk_counts, DeviceCounters* counters)
+{
+  const uint32_t n = counters->live[bounce];
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x * 256u >= n) return;
+  bool hit = false;
+  if (s < n) {
+    Ray ray = load_ray(paths, s);
+    Hit rec;
+    rec.t = -1.0f;
+    rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+    rec.mat = 0u;
+    rec.side = 0u;
+    bool changed = kFirst;
+    if (!kFirst) {
+      const float carried = hits.tp[s].x;
+      if (carried >= 0.0f) {
+        hit = true;
+        ray.tmax = carried;
+      }
+    }
+    for (uint32_t i = obj_begin; i < obj_end; ++i) {
+      const DObject* obj = sc.objects + i;
+      if (obj->type != 0u) continue;
+      if (!ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax))) continue;
+      Ray tr;
+      inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
+      tr.tmin = ray.tmin;
+      tr.tmax = ray.tmax;
+      const float4 sp = sc.spheres[obj->index];
+      if (ray_sphere(tr, xyz(sp), sp.w, rec)) {
+        rec.p = xform_point(obj->m, rec.p);
+        rec.t = length(rec.p - ray.o);
+        rec.n = xform_normal(obj->inv_m, rec.n);
+        rec.mat = sc.object_material[i];
+        ray.tmax = rec.t;
+        hit = true;
+        changed = true;
+      }
+    }
+    if (changed) {
+      hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
+      hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+    }
+  }
+  if (kLast) {
+    const uint64_t live = __ballot(hit);
+    if ((threadIdx.x & 63u) == 0u) chunk_counts[s / kChunk] = (uint32_t)__popcll(live);
   }
 }
 
@@ -964,6 +1254,32 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
   else
     hipLaunchKernelGGL(k_trace<false>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
                        chunk_counts, counters);
+}
+void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
+                    DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
+                    DeviceCounters* counters)
+{
+  const dim3 grid(div_up(max_paths, 256u)), block(256);
+  if (first && last)
+    hipLaunchKernelGGL((k_spheres<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+  else if (first)
+    hipLaunchKernelGGL((k_spheres<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+  else if (last)
+    hipLaunchKernelGGL((k_spheres<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+  else
+    hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+}
+void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves)
+{
+  const dim3 grid(waves), block(kWave);
+  if (count_tests) {
+    if (first) hipLaunchKernelGGL((k_traverse<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+    else hipLaunchKernelGGL((k_traverse<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+  } else {
+    if (first) hipLaunchKernelGGL((k_traverse<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+    else hipLaunchKernelGGL((k_traverse<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+  }
 }
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters)

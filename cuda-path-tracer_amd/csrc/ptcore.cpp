@@ -71,7 +71,14 @@ struct ptc_ctx {
   bool in_frame = false;
   uint64_t frames = 0;
 
-  int trace_variant = 1;  // 0: reference-order traversal, 1: culled near-first traversal (default)
+  int trace_variant = 2;  // 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
+  struct Segment {
+    bool mesh;
+    uint32_t begin, end;  // object range (mesh: one object)
+  };
+  std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
+  uint32_t traverse_waves = 4096;
+  int work_slot = 0;
 
   // measurement
   bool time_trace = false;
@@ -377,6 +384,20 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.root_ref = wa.root_ref;
   d.object_count = s->object_count;
   d.bvh_node_count = node_count;
+  // segments for the persistent pipeline: runs of spheres and single mesh objects, in object order
+  ctx->segments.clear();
+  for (uint32_t i = 0; i < s->object_count;) {
+    if (s->objects[i].type == 1u) {
+      if (node_count) ctx->segments.push_back({true, i, i + 1u});
+      ++i;
+    } else {
+      uint32_t j = i;
+      while (j < s->object_count && s->objects[j].type == 0u) ++j;
+      ctx->segments.push_back({false, i, j});
+      i = j;
+    }
+  }
+  if (ctx->segments.empty() || ctx->segments.back().mesh) ctx->segments.push_back({false, s->object_count, s->object_count});
   ctx->scene = d;
   ctx->has_scene = true;
   ctx->bvh_nodes = node_count;
@@ -474,7 +495,7 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 1) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
+  if (!ctx || variant < 0 || variant > 2) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
   ctx->trace_variant = variant;
   return PTC_OK;
 }
@@ -502,6 +523,7 @@ int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
   ctx->cam = make_camera(*camera, ctx->width, ctx->height);
   ctx->have_cam = true;
   ctx->cur = 0;
+  ctx->work_slot = 0;
   launch_raygen(ctx->stream, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count, ctx->paths[0], ctx->counters);
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->in_frame = true;
@@ -527,8 +549,27 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     }
     HIP_TRY(ctx, hipEventRecord(tl.start, ctx->stream));
   }
-  launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters,
-               ctx->count_tests, ctx->trace_variant);
+  if (ctx->trace_variant == 2) {
+    // closest hit = the object list walked as segments (see launch_spheres / launch_traverse)
+    for (size_t k = 0; k < ctx->segments.size(); ++k) {
+      const auto& seg = ctx->segments[k];
+      const bool first = k == 0, final_seg = k + 1 == ctx->segments.size();
+      if (seg.mesh) {
+        if (ctx->work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
+          HIP_TRY(ctx, hipMemsetAsync(&ctx->counters->work[0][0], 0, sizeof(uint32_t) * 8, ctx->stream));
+          ctx->work_slot = 0;
+        }
+        launch_traverse(ctx->stream, ctx->scene, seg.begin, first, in, ctx->hits, bounce, ctx->work_slot++, ctx->counters,
+                        ctx->count_tests, ctx->traverse_waves);
+      } else {
+        launch_spheres(ctx->stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, ctx->hits, ctx->pix_count, bounce,
+                       ctx->chunk_counts, ctx->counters);
+      }
+    }
+  } else {
+    launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters,
+                 ctx->count_tests, ctx->trace_variant);
+  }
   if (ctx->time_trace) {
     HIP_TRY(ctx, hipEventRecord(tl.stop, ctx->stream));
     ctx->timed.push_back(tl);
@@ -733,6 +774,7 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
     out->tri_tests[b] = host.tri_tests[b];
     out->trace_ms[b] = ctx->trace_ms[b];
     out->trace_launches[b] = ctx->trace_launches[b];
+    out->max_box_tests[b] = host.max_box_tests[b];
   }
   return PTC_OK;
 }
@@ -764,7 +806,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   hipError_t e = hipMemcpyAsync(ro, ho.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(rd, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->counters, ctx->trace_variant);
+    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->counters, ctx->trace_variant == 0 ? 0 : 1);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(tp.data(), hits.tp, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);

@@ -188,7 +188,8 @@ class PathTracer:
         n = self.max_bounces
         return {"paths": [int(x) for x in p.paths[:n]], "box_tests": [int(x) for x in p.box_tests[:n]],
                 "tri_tests": [int(x) for x in p.tri_tests[:n]], "trace_ms": [float(x) for x in p.trace_ms[:n]],
-                "trace_launches": [int(x) for x in p.trace_launches[:n]]}
+                "trace_launches": [int(x) for x in p.trace_launches[:n]],
+                "max_box_tests": [int(x) for x in p.max_box_tests[:n]]}
 
     def intersect_rays(self, rays):
         """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""

@@ -142,6 +142,7 @@ typedef struct ptc_profile {
   uint64_t tri_tests[PTC_MAX_BOUNCES_CAP];
   double trace_ms[PTC_MAX_BOUNCES_CAP];
   uint32_t trace_launches[PTC_MAX_BOUNCES_CAP];
+  uint32_t max_box_tests[PTC_MAX_BOUNCES_CAP]; /* longest single traversal seen (counting runs) */
 } ptc_profile;
 
 typedef struct ptc_ctx ptc_ctx;
@@ -175,9 +176,13 @@ int ptc_set_max_iterations(ptc_ctx* ctx, int max_iterations);       /* PathTrace
 int ptc_set_method(ptc_ctx* ctx, int method);                       /* PathTracer::current_gpu_method */
 int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces);             /* static max_bounces = 50, path_tracer.cu:27 */
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* PathTracer::atrous_denoiser */
-/* Closest-hit kernel variant: 1 (default) = culled, near-first traversal over the wide node layout;
- * 0 = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no t culling).
- * Both return the same hits (same box decisions, same tie rule); 0 exists to cross-check 1 on the GPU. */
+/* Closest-hit kernel variant:
+ *   2 (default) = culled near-first traversal over the wide node layout, persistent wavefronts whose lanes
+ *                 fetch the next ray as soon as their own is finished; objects walked as sphere / mesh segments
+ *   1           = the same traversal, one wavefront per 64 fixed paths
+ *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no
+ *                 t culling)
+ * All return the same hits (same box decisions, same tie rule); 0 and 1 exist to cross-check 2 on the GPU. */
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
 
 /* ---- the hot path ---- */

@@ -16,7 +16,8 @@ flat=sc.build_scene()
 mesh=list(sc.mesh_map_.values())[0]
 flat.bvh,depth=pkg.bvh_from_mesh(mesh)
 res={}
-for variant in (0,1):
+VARIANTS=tuple(int(v) for v in (sys.argv[3] if len(sys.argv)>3 else '0,1,2').split(','))
+for variant in VARIANTS:
     with pkg.PathTracer(max_bounces=8) as pt:
         pt.create_buffers((W,H), flat); pt.max_iterations=1<<30
         pt.set_trace_variant(variant)
@@ -31,7 +32,9 @@ for variant in (0,1):
         pt.set_profiling(False, True); pt.reset_profile(); pt.set_iteration(0); pt.path_trace(sc.camera); pr=pt.profile()
         rays=sum(pr['paths'])
         print(f"variant {variant}: {dt/K*1e3:.2f} ms/frame, live {st['last_live']}, box/ray {sum(pr['box_tests'])/rays:.1f} tri/ray {sum(pr['tri_tests'])/rays:.2f}", flush=True)
-for k in ('color','normal','depth'):
-    a,b=res[0][k],res[1][k]
-    print(k,'identical',np.array_equal(a,b),'ndiff',int(np.sum(a!=b)))
-print('live identical', res[0]['live']==res[1]['live'])
+base=VARIANTS[0]
+for v in VARIANTS[1:]:
+    for k in ('color','normal','depth'):
+        a,b=res[base][k],res[v][k]
+        print(f'variant {v} vs {base}:',k,'identical',np.array_equal(a,b),'ndiff',int(np.sum(a!=b)))
+    print(f'variant {v} vs {base}: live identical', res[base]['live']==res[v]['live'])
