@@ -77,7 +77,8 @@ class ptc_stats(C.Structure):
 class ptc_profile(C.Structure):
     _fields_ = [("paths", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("box_tests", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
                 ("tri_tests", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("trace_ms", C.c_double * PTC_MAX_BOUNCES_CAP),
-                ("trace_launches", C.c_uint32 * PTC_MAX_BOUNCES_CAP), ("max_box_tests", C.c_uint32 * PTC_MAX_BOUNCES_CAP)]
+                ("trace_launches", C.c_uint32 * PTC_MAX_BOUNCES_CAP), ("max_box_tests", C.c_uint32 * PTC_MAX_BOUNCES_CAP),
+                ("max_ray_cycles", C.c_uint32 * PTC_MAX_BOUNCES_CAP), ("max_wave_cycles", C.c_uint32 * PTC_MAX_BOUNCES_CAP)]
 
 
 # every symbol include/ptcore.h declares: name -> (restype, argtypes)
@@ -99,6 +100,7 @@ SIGNATURES = {
     "ptc_set_method": (C.c_int, [_P, C.c_int]),
     "ptc_set_max_bounces": (C.c_int, [_P, C.c_int]),
     "ptc_set_trace_variant": (C.c_int, [_P, C.c_int]),
+    "ptc_set_param": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "ptc_set_denoiser_params": (C.c_int, [_P, C.POINTER(ptc_denoiser_params)]),
     "ptc_trace": (C.c_int, [_P, C.POINTER(ptc_camera)]),
     "ptc_trace_begin": (C.c_int, [_P, C.POINTER(ptc_camera)]),

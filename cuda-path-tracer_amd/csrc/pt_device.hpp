@@ -13,7 +13,7 @@ constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kChunk = 64;           // paths per compaction chunk = one wavefront
 constexpr int kStackDepth = 64;      // traversal stack entries per ray (LDS, [depth][lane])
 constexpr int kMaxBounces = 64;      // == PTC_MAX_BOUNCES_CAP
-constexpr int kWorkSlots = 512;      // persistent traversal launches per frame that get their own fetch cursors
+constexpr int kWorkSlots = 128;      // persistent traversal launches per frame that get their own fetch cursors
 
 // error bits in DeviceCounters::flags
 constexpr uint32_t kFlagStackOverflow = 1u;
@@ -46,7 +46,16 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, n.xyz}   with p = transform_point(M, position),
 //           e1 = p1 - p0, e2 = p2 - p0, n = normalize(cross(e1, e2))   (exactly what the reference
 //           recomputes per test, path_tracer.cu:57-59, intersections.cuh:45-46,54-55)
+//   bvh4: the same tree collapsed to four children per node for the persistent traversal, 128 bytes per node
+//         (one cache line), component-major so four boxes are tested with vector code:
+//           q0..q2 = child min x / y / z [4]   q3..q5 = child max x / y / z [4]   q6 = refs[4]   q7 = unused
+//         ref = node index, kLeafBit | depth-first triangle rank, or kNoChild.  Nodes in depth-first preorder.
+//   leaf_parent: per triangle (depth-first rank) the box of the leaf's parent in the REFERENCE tree, 2 float4.
+//         Why it suffices for exactness: boxes nest exactly (parent = componentwise min/max of children) and
+//         IEEE subtraction/division are monotonic, so whenever a node passes the reference's box test all its
+//         ancestors pass too; a triangle is reachable in the reference iff its parent's box passes.
 constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoChild = 0xffffffffu;
 
 struct DScene {
   const DObject* objects;
@@ -59,6 +68,11 @@ struct DScene {
   const float4* wide;              // 4 float4 per inner node
   const float4* tris;              // 3 float4 per instance triangle
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
+  const float4* bvh4;              // 8 float4 per four-wide node
+  const float4* leaf_parent;       // 2 float4 per triangle
+  uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
+  uint32_t spill_stride;           // number of persistent threads
+  uint32_t bvh4_root;
   float root_min[3];               // box of the root (tested before descending, like any inner node)
   float root_max[3];
   uint32_t root_ref;               // record 0, or kLeafBit for a single-triangle mesh
@@ -110,7 +124,11 @@ struct DeviceCounters {
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
   unsigned long long tri_tests[kMaxBounces];
   uint32_t max_box_tests[kMaxBounces];        // longest single traversal (box tests of one ray), instrumented runs
-  uint32_t work[kWorkSlots][8];               // ray-fetch cursors of the persistent traversal launches (per image region)
+  uint32_t max_ray_cycles[kMaxBounces];       // longest single traversal in shader clocks (s_memtime), instrumented runs
+  uint32_t max_wave_cycles[kMaxBounces];      // longest-lived persistent wavefront, instrumented runs
+  // ray-fetch cursors of the persistent traversal launches, one per image region, each on its own 128-byte
+  // line (cursors sharing a line serialise in L2: measured ~30 atomics/us for the whole line)
+  uint32_t work[kWorkSlots][8][32];
 };
 
 struct DDenoise {
@@ -131,7 +149,7 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
                     DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
                     DeviceCounters* counters);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves);
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

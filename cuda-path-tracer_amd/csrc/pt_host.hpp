@@ -32,6 +32,17 @@ struct WideAccel {
 };
 int build_wide(const ptc_bvh_node* nodes, uint32_t count, WideAccel& out);
 
+// Four-wide collapse of the reference tree for the persistent traversal (see DScene::bvh4 in pt_device.hpp).
+struct Wide4Accel {
+  std::vector<float4> nodes;        // 8 per node, depth-first preorder
+  std::vector<float4> leaf_parent;  // 2 per triangle (depth-first leaf order): box of the leaf's parent node
+  uint32_t root_ref = 0;
+  uint32_t depth = 0;               // levels of four-wide nodes above the deepest leaf
+  uint32_t node_count = 0;
+};
+// leaf_rank comes from build_wide (same depth-first leaf order as WideAccel::tri_order)
+int build_wide4(const ptc_bvh_node* nodes, uint32_t count, Wide4Accel& out);
+
 // World-space triangles of one instance in depth-first leaf order: 3 float4 per triangle.
 void build_instance_triangles(const m4& m, const float* positions, const uint32_t* indices,
                               const std::vector<uint32_t>& tri_order, float4* out);

@@ -136,7 +136,7 @@ __device__ __forceinline__ void inverse_transform_ray(const m4& inv_m, const Ray
 // [depth][lane] so that a push or pop of the whole wavefront touches 64 consecutive banks.
 template <bool kCount>
 __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObject* obj, Hit& rec, uint32_t* stack,
-                                         uint32_t& flags, Tally& tally)
+                                         uint32_t& flags, Tally& tally, const int stack_cap = kStackDepth)
 {
   bool hit = false;
   f3 oo, od;
@@ -164,7 +164,7 @@ __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObjec
         ray.tmax = rec.t;
       }
     } else if ((kCount ? (void)++tally.boxes : (void)0), ray_aabb(oo, od, xyz(n0), xyz(n1))) {
-      if (sp + 2 > kStackDepth) {
+      if (sp + 2 > stack_cap) {
         flags |= kFlagStackOverflow;
       } else {
         stack[sp * kWave] = first + 1u;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration,
     counters->live[0] = pix_count;
   }
   if (blockIdx.x == 0u)  // fetch cursors of this frame's persistent traversal launches
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0])[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0][0])[i * 32u] = 0u;
   if (s >= pix_count) return;
   const uint32_t pixel = pix_begin + s;
   const uint32_t x = pixel % cam.width, y = pixel / cam.width;
@@ -677,6 +677,66 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 // device-side cursor.  Results are written per slot, so the order in which rays are processed is
 // irrelevant to the output.  One launch handles ONE mesh object (its matrices stay in scalar registers);
 // the closest hit so far travels in the hit record between the segments of a bounce.
+// Ray hand-out for the persistent traversal kernels.  The live paths [0, n) are cut into eight image regions
+// (one per XCD: blockIdx % 8) and each region into 64-ray batches.  The first 7/8 of a region's batches are
+// dealt statically, interleaved over the region's wavefronts (no atomics, spatially balanced); the rest is
+// taken dynamically from one cursor per region (own 128-byte line) so that wavefronts that finish early keep
+// the others' tail short; a wavefront whose region is used up moves on to the next one.
+struct RayFeed {
+  uint32_t n, region_size, waves_per_region, home, region, tried, stat_next;
+  uint32_t* cursors;  // [8][32]
+  bool in_static;
+
+  __device__ __forceinline__ uint32_t region_len(uint32_t r) const
+  {
+    const uint32_t b = r * region_size;
+    return b < n ? min(n - b, region_size) : 0u;
+  }
+  __device__ __forceinline__ uint32_t static_batches(uint32_t r) const { return ((region_len(r) + kWave - 1u) / kWave) * 7u / 8u; }
+  __device__ __forceinline__ void init(uint32_t n_, uint32_t* cursors_)
+  {
+    n = n_;
+    cursors = cursors_;
+    region_size = ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave;
+    waves_per_region = (gridDim.x + 7u) / 8u;
+    home = region = blockIdx.x & 7u;
+    stat_next = blockIdx.x >> 3;
+    tried = 0u;
+    in_static = true;
+  }
+  __device__ __forceinline__ bool exhausted() const { return !in_static && tried >= 8u; }
+  // wave-uniform: next batch [begin, end) or false
+  __device__ __forceinline__ bool acquire(uint32_t& begin, uint32_t& end)
+  {
+    if (in_static) {
+      if (stat_next < static_batches(home)) {
+        begin = home * region_size + stat_next * kWave;
+        end = begin + kWave;  // static batches are full batches inside the region
+        stat_next += waves_per_region;
+        return true;
+      }
+      in_static = false;
+    }
+    while (tried < 8u) {
+      const uint32_t len = region_len(region);
+      const uint32_t first = static_batches(region) * kWave;
+      uint32_t base = len;
+      if (threadIdx.x == 0u && first < len &&
+          first + __hip_atomic_load(&cursors[region * 32u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len)
+        base = first + atomicAdd(&cursors[region * 32u], (uint32_t)kWave);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base < len) {
+        begin = region * region_size + base;
+        end = region * region_size + min(len, base + kWave);
+        return true;
+      }
+      region = (region + 1u) & 7u;
+      ++tried;
+    }
+    return false;
+  }
+};
+
 constexpr uint32_t kRefillLanes = 20u;  // fetch new rays once this many lanes are idle
 
 template <bool kCount, bool kFirst>
@@ -690,15 +750,9 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
-  // Eight image regions, one fetch cursor each; a wavefront starts in the region of its XCD (blockIdx % 8)
-  // and moves on when a region is used up.  Rays are reserved in batches (one atomic per batch: a single
-  // counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue") and handed to idle lanes
-  // from the wavefront's private range.
-  const uint32_t region_size = ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave;
-  const uint32_t per_wave = n / gridDim.x;
-  const uint32_t batch = per_wave >= 256u ? 256u : (per_wave >= 128u ? 128u : (uint32_t)kWave);
-  if (blockIdx.x >= (n + batch - 1u) / batch + 8u) return;  // more wavefronts than batches: nothing to do
-  uint32_t region = blockIdx.x & 7u, regions_tried = 0u;
+  if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
+  RayFeed feed;
+  feed.init(n, &counters->work[work_slot][0][0]);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;
@@ -713,24 +767,9 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
   for (;;) {
     const uint64_t idle_mask = __ballot(!active);
     const uint32_t idle = (uint32_t)__popcll(idle_mask);
-    const bool more = priv_next < priv_end || regions_tried < 8u;
+    const bool more = priv_next < priv_end || !feed.exhausted();
     if (more && (idle == (uint32_t)kWave || idle >= kRefillLanes)) {
-      while (priv_next >= priv_end && regions_tried < 8u) {
-        const uint32_t region_begin = region * region_size;
-        const uint32_t region_len = region_begin < n ? min(n - region_begin, region_size) : 0u;
-        uint32_t base = region_len;
-        if (threadIdx.x == 0u && region_len != 0u &&
-            __hip_atomic_load(&counters->work[work_slot][region], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < region_len)
-          base = atomicAdd(&counters->work[work_slot][region], batch);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= region_len) {
-          region = (region + 1u) & 7u;  // used up: help with the next region
-          ++regions_tried;
-        } else {
-          priv_next = region_begin + base;
-          priv_end = region_begin + min(region_len, base + batch);
-        }
-      }
+      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
       const uint32_t mine = priv_next + rank_below(idle_mask);
       const uint32_t range_end = priv_end;
       priv_next = min(priv_end, priv_next + idle);
@@ -772,7 +811,7 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
       }
     }
     if (__ballot(active) == 0ull) {
-      if (priv_next >= priv_end && regions_tried >= 8u) break;
+      if (priv_next >= priv_end && feed.exhausted()) break;
       continue;
     }
 
@@ -881,6 +920,262 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
     if (threadIdx.x == 0u) {
       atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
       atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// variant 3: persistent traversal over the four-wide collapse, exactness restored per candidate
+// ------------------------------------------------------------------------------------------------
+// Because a node that passes the reference's box test implies that all its ancestors pass (boxes nest
+// exactly; IEEE - and / are monotonic), the reference's result for one mesh is: the closest accepted
+// triangle among those whose PARENT box passes the exact test (ties: later in depth-first order).  So the
+// traversal itself only has to be conservative -- never skip a subtree that could hold such a triangle -- and
+// is free to use another node layout: here the reference tree collapsed to four children per 128-byte node
+// (half the dependent loads per ray).  A candidate that survives the triangle test is then checked against
+// its parent's box with the reference's own arithmetic before it is accepted.
+// Rays with a zero / subnormal direction component (0/0 = NaN in the reference's slab test breaks the
+// nesting argument) take the reference-order traversal instead.
+constexpr int kLdsStack = 16;    // (ref, effective near distance) pairs per lane in LDS: 8 KiB per wavefront
+constexpr int kSpillStack = 48;  // further entries per lane in global memory (DScene::spill)
+
+template <bool kCount, bool kFirst>
+__global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
+                                                     int work_slot, DeviceCounters* counters)
+{
+  __shared__ uint2 s_stack[kLdsStack * kWave];
+  const uint32_t n = counters->live[bounce];
+  if (n == 0u) return;
+  const DObject* obj = sc.objects + obj_index;
+  const uint32_t mat = sc.object_material[obj_index];
+  const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
+  const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
+
+  if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
+  RayFeed feed;
+  feed.init(n, &counters->work[work_slot][0][0]);
+  uint32_t priv_next = 0u, priv_end = 0u;
+
+  bool active = false;
+  uint32_t slot = 0u, cur = 0u, flags = 0u;
+  int sp = 0, best_k = -1;
+  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
+  Tally tally;
+  uint32_t ray_boxes = 0u;
+  unsigned long long ray_start = 0ull;
+  const unsigned long long wave_start = kCount ? __builtin_readcyclecounter() : 0ull;
+
+  auto push = [&](uint32_t ref, float eff_near) {
+    const uint2 e = make_uint2(ref, __float_as_uint(eff_near));
+    if (sp < kLdsStack) s_stack[sp * kWave + threadIdx.x] = e;
+    else if (sp < kLdsStack + kSpillStack && sc.spill) sc.spill[(size_t)(sp - kLdsStack) * sc.spill_stride + gid] = e;
+    else {
+      flags |= kFlagStackOverflow;
+      return;
+    }
+    ++sp;
+  };
+  // next entry whose box is not already beyond the closest hit; false when the stack is empty
+  auto pop = [&]() -> bool {
+    while (sp > 0) {
+      --sp;
+      const uint2 e = sp < kLdsStack ? s_stack[sp * kWave + threadIdx.x]
+                                     : sc.spill[(size_t)(sp - kLdsStack) * sc.spill_stride + gid];
+      if (__uint_as_float(e.y) > limit * 1.001f) continue;
+      cur = e.x;
+      return true;
+    }
+    return false;
+  };
+
+  for (;;) {
+    const uint64_t idle_mask = __ballot(!active);
+    const uint32_t idle = (uint32_t)__popcll(idle_mask);
+    const bool more = priv_next < priv_end || !feed.exhausted();
+    if (more && (idle == (uint32_t)kWave || idle >= kRefillLanes)) {
+      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
+      const uint32_t mine = priv_next + rank_below(idle_mask);
+      const uint32_t range_end = priv_end;
+      priv_next = min(priv_end, priv_next + idle);
+      if (!active && mine < range_end) {
+        slot = mine;
+        const float4 o4 = paths.o4[slot];
+        const float4 d4 = paths.d4[slot];
+        ro = xyz(o4);
+        rd = xyz(d4);
+        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
+        float t_in = FLT_MAX;
+        if (!kFirst) {
+          const float carried = hits.tp[slot].x;
+          if (carried >= 0.0f) t_in = carried;
+        }
+        bool go = sc.bvh_node_count != 0u && ray_aabb(ro, rd, ld3(obj->bmin), ld3(obj->bmax));  // path_tracer.cu:84
+        bool wrote = false;
+        if (go) {
+          const f3 v = xform_vector(obj->inv_m, rd);  // inverse_transform_ray, transform.hpp:51-58
+          scale = ieee_sqrt(dot(v, v));
+          const f3 od = v * (1.0f / scale);
+          oo = xform_point(obj->inv_m, ro);
+          inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)), 0)) {
+            // degenerate direction: the reference-order traversal, in place (rare)
+            Ray ray;
+            ray.o = ro;
+            ray.d = rd;
+            ray.tmin = tmin;
+            ray.tmax = t_in;
+            Hit rec;
+            rec.t = 0.0f;
+            rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+            rec.mat = 0u;
+            rec.side = 0u;
+            Tally unused;
+            if (ray_mesh<false>(ray, sc, obj, rec, reinterpret_cast<uint32_t*>(s_stack) + threadIdx.x, flags, unused,
+                                2 * kLdsStack)) {
+              hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
+              hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(mat | (rec.side << 31)));
+              wrote = true;
+            }
+            go = false;
+          } else {
+            best_t = t_in;
+            best_k = -1;
+            limit = scale * best_t;
+            cur = sc.bvh4_root;
+            sp = 0;
+            ray_boxes = 0u;
+            if (kCount) ray_start = __builtin_readcyclecounter();
+          }
+        }
+        if (go) active = true;
+        else if (kFirst && !wrote) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (__ballot(active) == 0ull) {
+      if (priv_next >= priv_end && feed.exhausted()) break;
+      continue;
+    }
+
+    bool done = false;
+    uint32_t leaf_refs[4] = {kNoChild, kNoChild, kNoChild, kNoChild};
+    uint32_t leaf_mask = 0u;
+    if (active) {
+      if (cur & kLeafBit) {  // only a single-triangle mesh starts at a leaf
+        leaf_refs[0] = cur;
+        leaf_mask = 1u;
+        cur = kNoChild;
+      } else {
+        const float4* q = sc.bvh4 + 8u * (size_t)cur;
+        const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5], rf = q[6];
+        float key[4];
+        uint32_t ref[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
+        const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w};
+        const float lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
+        const float hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, hi_z[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float ax = (lo_x[c] - oo.x) * inv.x, bx = (hi_x[c] - oo.x) * inv.x;
+          const float ay = (lo_y[c] - oo.y) * inv.y, by = (hi_y[c] - oo.y) * inv.y;
+          const float az = (lo_z[c] - oo.z) * inv.z, bz = (hi_z[c] - oo.z) * inv.z;
+          const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+          const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+          const bool valid = ref[c] != kNoChild;
+          const bool leaf = (ref[c] & kLeafBit) != 0u;
+          // skip only what is missed by far more than rounding (conservative), or lies beyond the closest
+          // hit / behind the origin with a margin
+          const float tol = (leaf ? 1e-4f : 1e-5f) * (fabsf(tn) + fabsf(tf)) + 1e-30f;
+          const bool go = valid && !((tf - tn) < -tol) && !box_culled(tn, tf, limit);
+          if (kCount && valid) { ++tally.boxes; ++ray_boxes; }
+          if (go && leaf) {
+            leaf_refs[c] = ref[c];
+            leaf_mask |= 1u << c;
+          }
+          key[c] = (go && !leaf) ? tn - 1e-3f * (tf - tn) : __builtin_inff();
+        }
+        // sort the (up to four) inner children by entry distance: 5 compare-exchanges
+        auto cx = [&](int a, int b) {
+          if (key[b] < key[a]) {
+            const float tk = key[a];
+            key[a] = key[b];
+            key[b] = tk;
+            const uint32_t tr = ref[a];
+            ref[a] = ref[b];
+            ref[b] = tr;
+          }
+        };
+        cx(0, 1);
+        cx(2, 3);
+        cx(0, 2);
+        cx(1, 3);
+        cx(1, 2);
+        if (key[3] < __builtin_inff()) push(ref[3], key[3]);
+        if (key[2] < __builtin_inff()) push(ref[2], key[2]);
+        if (key[1] < __builtin_inff()) push(ref[1], key[1]);
+        cur = key[0] < __builtin_inff() ? ref[0] : kNoChild;
+      }
+      // triangles of the leaf children that survived (ray_triangle_intersection_test, intersections.cuh:49-85)
+      while (leaf_mask) {
+        const int c = __builtin_ctz(leaf_mask);
+        leaf_mask &= leaf_mask - 1u;
+        const uint32_t k = (c == 0 ? leaf_refs[0] : c == 1 ? leaf_refs[1] : c == 2 ? leaf_refs[2] : leaf_refs[3]) & ~kLeafBit;
+        const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
+        if (kCount) ++tally.tris;
+        const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
+        const f3 h = cross(rd, e2);
+        const float a = dot(e1, h);
+        if (a > -0.0000001f && a < 0.0000001f) continue;
+        const float f = 1.0f / a;
+        const f3 sv = ro - p0;
+        const float u = f * dot(sv, h);
+        if (u < 0.0f || u > 1.0f) continue;
+        const f3 qv = cross(sv, e1);
+        const float w = f * dot(rd, qv);
+        if (w < 0.0f || u + w > 1.0f) continue;
+        const float t = f * dot(e2, qv);
+        if (t < tmin || !(t < best_t || (t == best_t && (int)k > best_k))) continue;
+        // reachable in the reference?  <=> the parent's box passes the reference's own test
+        const float4 pb0 = sc.leaf_parent[2u * (size_t)k], pb1 = sc.leaf_parent[2u * (size_t)k + 1u];
+        const f3 od = normalize(xform_vector(obj->inv_m, rd));
+        float en, ef;
+        if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef)) continue;
+        best_t = t;
+        best_k = (int)k;
+        limit = scale * t;
+      }
+      if (cur == kNoChild && !pop()) done = true;
+    }
+    if (done) {
+      if (best_k >= 0) {
+        const float4 tc = tris[3u * (size_t)best_k + 2u];
+        const f3 outward = mk3(tc.y, tc.z, tc.w);
+        const f3 p = ro + rd * best_t;
+        const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
+        const f3 nn = side == 0u ? outward : -outward;
+        hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
+        hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+      } else if (kFirst) {
+        hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      }
+      if (kCount) {
+        atomicMax(&counters->max_box_tests[bounce], ray_boxes);
+        atomicMax(&counters->max_ray_cycles[bounce], (uint32_t)(__builtin_readcyclecounter() - ray_start));
+      }
+      active = false;
+    }
+  }
+  if (flags) atomicOr(&counters->flags, flags);
+  if (kCount) {
+    uint32_t b = tally.boxes, t = tally.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off, 64);
+      t += __shfl_down(t, off, 64);
+    }
+    if (threadIdx.x == 0u) {
+      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
+      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+      atomicMax(&counters->max_wave_cycles[bounce], (uint32_t)(__builtin_readcyclecounter() - wave_start));
     }
   }
 }
@@ -1270,9 +1565,19 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
     hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves)
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant)
 {
   const dim3 grid(waves), block(kWave);
+  if (variant == 3) {
+    if (count_tests) {
+      if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+      else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+    } else {
+      if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+      else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+    }
+    return;
+  }
   if (count_tests) {
     if (first) hipLaunchKernelGGL((k_traverse<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
     else hipLaunchKernelGGL((k_traverse<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);

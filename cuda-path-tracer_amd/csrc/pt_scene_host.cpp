@@ -3,6 +3,7 @@
 #include "pt_device.hpp"
 
 #include <cfloat>
+#include <algorithm>
 #include <cstring>
 
 namespace pt {
@@ -189,6 +190,125 @@ int build_wide(const ptc_bvh_node* nodes, uint32_t count, WideAccel& out)
     out.root_min[k] = nodes[0].aabb_min[k];
     out.root_max[k] = nodes[0].aabb_max[k];
   }
+  return PTC_OK;
+}
+
+namespace {
+
+struct Collapse {
+  const ptc_bvh_node* nodes;
+  const std::vector<uint32_t>& leaf_rank;
+  Wide4Accel& out;
+  uint32_t deepest = 0;
+
+  static float area(const ptc_bvh_node& n)
+  {
+    const float dx = n.aabb_max[0] - n.aabb_min[0], dy = n.aabb_max[1] - n.aabb_min[1], dz = n.aabb_max[2] - n.aabb_min[2];
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+  }
+
+  // returns the child reference of reference-tree node i
+  uint32_t emit(uint32_t i, uint32_t level)
+  {
+    if (nodes[i].primitive_count != 0u) return kLeafBit | leaf_rank[i];
+    const uint32_t idx = (uint32_t)(out.nodes.size() / 8u);
+    out.nodes.resize(out.nodes.size() + 8u);
+    deepest = std::max(deepest, level + 1u);
+    // children: start with the two children, open the inner child with the largest surface area until four;
+    // a child is replaced IN PLACE by (left, right) so the left-to-right order stays the depth-first order
+    uint32_t kids[4];
+    int nk = 2;
+    kids[0] = nodes[i].first_child_or_primitive;
+    kids[1] = kids[0] + 1u;
+    while (nk < 4) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (int k = 0; k < nk; ++k)
+        if (nodes[kids[k]].primitive_count == 0u && area(nodes[kids[k]]) > best_area) {
+          best_area = area(nodes[kids[k]]);
+          best = k;
+        }
+      if (best < 0) break;
+      const uint32_t l = nodes[kids[best]].first_child_or_primitive;
+      for (int k = nk; k > best + 1; --k) kids[k] = kids[k - 1];
+      kids[best] = l;
+      kids[best + 1] = l + 1u;
+      ++nk;
+    }
+    float lo[3][4], hi[3][4];
+    uint32_t refs[4];
+    for (int k = 0; k < 4; ++k) {
+      if (k < nk) {
+        for (int a = 0; a < 3; ++a) {
+          lo[a][k] = nodes[kids[k]].aabb_min[a];
+          hi[a][k] = nodes[kids[k]].aabb_max[a];
+        }
+        refs[k] = emit(kids[k], level + 1u);
+      } else {
+        for (int a = 0; a < 3; ++a) {
+          lo[a][k] = 0.0f;
+          hi[a][k] = 0.0f;
+        }
+        refs[k] = kNoChild;
+      }
+    }
+    auto bits = [](uint32_t u) {
+      float f;
+      std::memcpy(&f, &u, 4);
+      return f;
+    };
+    float4* w = &out.nodes[(size_t)idx * 8u];
+    for (int a = 0; a < 3; ++a) {
+      w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+      w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    w[6] = make_float4(bits(refs[0]), bits(refs[1]), bits(refs[2]), bits(refs[3]));
+    w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return idx;
+  }
+};
+
+}  // namespace
+
+int build_wide4(const ptc_bvh_node* nodes, uint32_t count, Wide4Accel& out)
+{
+  out = Wide4Accel{};
+  if (count == 0) return PTC_OK;
+  // depth-first (left-first) leaf ranks and each leaf's parent box
+  std::vector<uint32_t> leaf_rank(count, 0u);
+  std::vector<uint32_t> parent(count, 0xffffffffu);
+  for (uint32_t i = 0; i < count; ++i)
+    if (nodes[i].primitive_count == 0u) {
+      parent[nodes[i].first_child_or_primitive] = i;
+      parent[nodes[i].first_child_or_primitive + 1u] = i;
+    }
+  uint32_t leaves = 0;
+  {
+    std::vector<uint32_t> stack{0u};
+    while (!stack.empty()) {
+      const uint32_t i = stack.back();
+      stack.pop_back();
+      if (nodes[i].primitive_count != 0u) {
+        leaf_rank[i] = leaves++;
+        const bool has_parent = parent[i] != 0xffffffffu;
+        const ptc_bvh_node& p = nodes[has_parent ? parent[i] : i];
+        // a single-triangle mesh has no inner node at all: every box test of the reference is vacuous
+        const float big = 3.402823466e+38f;
+        out.leaf_parent.push_back(has_parent ? make_float4(p.aabb_min[0], p.aabb_min[1], p.aabb_min[2], 0.f)
+                                             : make_float4(-big, -big, -big, 0.f));
+        out.leaf_parent.push_back(has_parent ? make_float4(p.aabb_max[0], p.aabb_max[1], p.aabb_max[2], 0.f)
+                                             : make_float4(big, big, big, 0.f));
+      } else {
+        stack.push_back(nodes[i].first_child_or_primitive + 1u);
+        stack.push_back(nodes[i].first_child_or_primitive);
+      }
+    }
+  }
+  out.nodes.reserve((size_t)count / 2u * 8u);
+  Collapse c{nodes, leaf_rank, out};
+  out.root_ref = c.emit(0u, 0u);
+  out.depth = c.deepest;
+  out.node_count = (uint32_t)(out.nodes.size() / 8u);
   return PTC_OK;
 }
 

@@ -42,7 +42,7 @@ struct ptc_ctx {
   std::vector<void*> scene_allocs;
   DScene scene{};
   bool has_scene = false;
-  uint32_t bvh_nodes = 0, bvh_depth = 0, triangles = 0;
+  uint32_t bvh_nodes = 0, bvh_depth = 0, triangles = 0, bvh4_nodes = 0, bvh4_depth = 0;
 
   // frame
   uint32_t width = 0, height = 0;
@@ -71,7 +71,7 @@ struct ptc_ctx {
   bool in_frame = false;
   uint64_t frames = 0;
 
-  int trace_variant = 2;  // 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
+  int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse (default); 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
   struct Segment {
     bool mesh;
     uint32_t begin, end;  // object range (mesh: one object)
@@ -379,6 +379,18 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   }
   if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
+  Wide4Accel w4;
+  if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh4, w4.nodes.data(), w4.nodes.size())) return rc;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
+  d.bvh4_root = w4.root_ref;
+  d.spill = nullptr;
+  d.spill_stride = ctx->traverse_waves * kWave;
+  if (node_count && 3u * w4.depth + 1u > 16u) {  // depth-first over four children: at most 3 pushes per level
+    if (int rc = dev_alloc(ctx, ctx->scene_allocs, &d.spill, (size_t)48 * d.spill_stride)) return rc;
+  }
+  ctx->bvh4_nodes = w4.node_count;
+  ctx->bvh4_depth = w4.depth;
   std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
   std::memcpy(d.root_max, wa.root_max, sizeof d.root_max);
   d.root_ref = wa.root_ref;
@@ -495,9 +507,21 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 2) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
+  if (!ctx || variant < 0 || variant > 3) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
   ctx->trace_variant = variant;
   return PTC_OK;
+}
+
+int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
+{
+  if (!ctx || !name) return PTC_ERR_INVALID;
+  if (std::strcmp(name, "traverse_waves") == 0) {
+    if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "traverse_waves out of range");
+    if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set traverse_waves before ptc_upload_scene");
+    ctx->traverse_waves = (uint32_t)value;
+    return PTC_OK;
+  }
+  return fail(ctx, PTC_ERR_INVALID, std::string("unknown parameter ") + name);
 }
 
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p)
@@ -549,18 +573,18 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     }
     HIP_TRY(ctx, hipEventRecord(tl.start, ctx->stream));
   }
-  if (ctx->trace_variant == 2) {
+  if (ctx->trace_variant >= 2) {
     // closest hit = the object list walked as segments (see launch_spheres / launch_traverse)
     for (size_t k = 0; k < ctx->segments.size(); ++k) {
       const auto& seg = ctx->segments[k];
       const bool first = k == 0, final_seg = k + 1 == ctx->segments.size();
       if (seg.mesh) {
         if (ctx->work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
-          HIP_TRY(ctx, hipMemsetAsync(&ctx->counters->work[0][0], 0, sizeof(uint32_t) * 8, ctx->stream));
+          HIP_TRY(ctx, hipMemsetAsync(&ctx->counters->work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, ctx->stream));
           ctx->work_slot = 0;
         }
         launch_traverse(ctx->stream, ctx->scene, seg.begin, first, in, ctx->hits, bounce, ctx->work_slot++, ctx->counters,
-                        ctx->count_tests, ctx->traverse_waves);
+                        ctx->count_tests, ctx->traverse_waves, ctx->trace_variant);
       } else {
         launch_spheres(ctx->stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, ctx->hits, ctx->pix_count, bounce,
                        ctx->chunk_counts, ctx->counters);
@@ -775,6 +799,8 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
     out->trace_ms[b] = ctx->trace_ms[b];
     out->trace_launches[b] = ctx->trace_launches[b];
     out->max_box_tests[b] = host.max_box_tests[b];
+    out->max_ray_cycles[b] = host.max_ray_cycles[b];
+    out->max_wave_cycles[b] = host.max_wave_cycles[b];
   }
   return PTC_OK;
 }

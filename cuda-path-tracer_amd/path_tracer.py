@@ -176,6 +176,9 @@ class PathTracer:
     def set_trace_variant(self, variant):
         self._check(self._lib.ptc_set_trace_variant(self._ctx, int(variant)))
 
+    def set_param(self, name, value):
+        self._check(self._lib.ptc_set_param(self._ctx, name.encode(), int(value)))
+
     def set_profiling(self, time_trace_kernel=False, count_tests=False):
         self._check(self._lib.ptc_set_profiling(self._ctx, int(time_trace_kernel), int(count_tests)))
 
@@ -189,7 +192,9 @@ class PathTracer:
         return {"paths": [int(x) for x in p.paths[:n]], "box_tests": [int(x) for x in p.box_tests[:n]],
                 "tri_tests": [int(x) for x in p.tri_tests[:n]], "trace_ms": [float(x) for x in p.trace_ms[:n]],
                 "trace_launches": [int(x) for x in p.trace_launches[:n]],
-                "max_box_tests": [int(x) for x in p.max_box_tests[:n]]}
+                "max_box_tests": [int(x) for x in p.max_box_tests[:n]],
+                "max_ray_cycles": [int(x) for x in p.max_ray_cycles[:n]],
+                "max_wave_cycles": [int(x) for x in p.max_wave_cycles[:n]]}
 
     def intersect_rays(self, rays):
         """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""

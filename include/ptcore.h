@@ -143,6 +143,8 @@ typedef struct ptc_profile {
   double trace_ms[PTC_MAX_BOUNCES_CAP];
   uint32_t trace_launches[PTC_MAX_BOUNCES_CAP];
   uint32_t max_box_tests[PTC_MAX_BOUNCES_CAP]; /* longest single traversal seen (counting runs) */
+  uint32_t max_ray_cycles[PTC_MAX_BOUNCES_CAP];  /* ... in shader clocks, and the longest-lived wavefront */
+  uint32_t max_wave_cycles[PTC_MAX_BOUNCES_CAP];
 } ptc_profile;
 
 typedef struct ptc_ctx ptc_ctx;
@@ -184,6 +186,9 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
  *                 t culling)
  * All return the same hits (same box decisions, same tie rule); 0 and 1 exist to cross-check 2 on the GPU. */
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
+/* Tuning knobs (speed only, never results).  Known names: "traverse_waves" = persistent wavefronts launched per
+ * traversal segment (default 4096; set before ptc_upload_scene). */
+int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
 /* ---- the hot path ---- */
 /* PathTracer::path_trace (path_tracer.cu:389-477): one sample per pixel, accumulated as a running
