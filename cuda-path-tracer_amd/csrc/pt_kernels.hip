@@ -1276,9 +1276,13 @@ __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, cons
 
 // material_kernel (path_tracer.cu:292-315) + the stable compaction scatter + the final gather of
 // every path that ends at this bounce.
-__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, uint32_t iteration, int bounce,
-                                               int last_bounce, const uint32_t* slot_base, const uint32_t* chunk_offsets,
-                                               DFrame fb, uint32_t pix_begin, DeviceCounters* counters)
+// acc_iteration: the sample index used for the running mean into `fb`.  With several frames in flight `fb` is
+// this frame's staging buffer and acc_iteration is 0 (plain store); k_accumulate then folds the staged
+// sample into the real framebuffer in iteration order.
+__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, uint32_t iteration,
+                                               uint32_t acc_iteration, int bounce, int last_bounce,
+                                               const uint32_t* slot_base, const uint32_t* chunk_offsets, DFrame fb,
+                                               uint32_t pix_begin, DeviceCounters* counters)
 {
   const uint32_t n = counters->live[bounce];
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
@@ -1303,12 +1307,12 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
     if (tp.x < 0.0f) {
       // miss: throughput *= sky; the path ends (path_tracer.cu:304-307, 283-289)
       color = color * background(rd);
-      if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, iteration, -rd, 1e6f);  // raygen defaults, ray_gen.cu:26-28
-      accumulate_color(fb.color4, local_pixel, iteration, color);
+      if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, -rd, 1e6f);  // raygen defaults, ray_gen.cu:26-28
+      accumulate_color(fb.color4, local_pixel, acc_iteration, color);
     } else {
       const float4 nm = hits.nm[s];
       const f3 hn = xyz(nm);
-      if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, iteration, hn, tp.x);  // path_tracer.cu:308-311
+      if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, hn, tp.x);  // path_tracer.cu:308-311
       const uint32_t ms = __float_as_uint(nm.w);
       const DMaterial m = sc.materials[ms & 0x7fffffffu];
       // RNG re-seeded from the global slot index, then discard(bounce) (path_tracer.cu:300-301)
@@ -1319,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
       const f3 hp = mk3(tp.y, tp.z, tp.w);
       evaluate_material(ro, rd, tmin_flag, hp, hn, ms >> 31, m, rng, color);
       if (last_bounce) {
-        accumulate_color(fb.color4, local_pixel, iteration, color);  // capped paths deposit raw throughput
+        accumulate_color(fb.color4, local_pixel, acc_iteration, color);  // capped paths deposit raw throughput
       } else {
         survives = true;
         pixbits = pixel | (tmin_flag ? 0x80000000u : 0u);
@@ -1335,6 +1339,16 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   }
 }
 
+
+// final_gather (path_tracer.cu:203-219) of one staged sample into the accumulated framebuffers
+__global__ __launch_bounds__(256) void k_accumulate(uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= pix_count) return;
+  const float4 c = stage.color4[i], g = stage.nd4[i];
+  accumulate_color(fb.color4, i, iteration, mk3(c.x, c.y, c.z));
+  accumulate_nd(fb.nd4, i, iteration, mk3(g.x, g.y, g.z), g.w);
+}
 
 // path_tracing_mega_kernel, path_tracer.cu:227-269: the whole path in one thread, one RNG stream per
 // pixel (a different image from streaming mode at the same seed -- a property of the reference).
@@ -1593,11 +1607,15 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
                      counters);
 }
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
-                  uint32_t iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
+                  uint32_t iteration, uint32_t acc_iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
                   const uint32_t* chunk_offsets, DFrame fb, uint32_t pix_begin, DeviceCounters* counters)
 {
-  hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u)), dim3(256), 0, s, scene, in, out, hits, iteration, bounce,
-                     last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, pix_begin, counters);
+  hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u)), dim3(256), 0, s, scene, in, out, hits, iteration,
+                     acc_iteration, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, pix_begin, counters);
+}
+void launch_accumulate(hipStream_t s, uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count)
+{
+  hipLaunchKernelGGL(k_accumulate, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, iteration, stage, fb, pix_count);
 }
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, uint32_t pix_begin,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters)

@@ -48,18 +48,38 @@ struct ptc_ctx {
   uint32_t width = 0, height = 0;
   uint32_t pix_begin = 0, pix_count = 0, pix_capacity = 0;
   std::vector<void*> frame_allocs;
-  DPaths paths[2]{};
-  int cur = 0;
-  DHits hits{};
-  uint32_t* chunk_counts = nullptr;
-  uint32_t* chunk_offsets = nullptr;
+  // Frames in flight: consecutive iterations are independent until they are folded into the framebuffer, and
+  // the tail of every bounce is a handful of long rays (latency-bound), so iteration i runs on stream i % F
+  // with its own path state and staging buffers; k_accumulate folds the staged samples in iteration order.
+  struct FrameSlot {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DPaths paths[2]{};
+    DHits hits{};
+    uint32_t* chunk_counts = nullptr;
+    uint32_t* chunk_offsets = nullptr;
+    DFrame stage{};
+    DeviceCounters* counters = nullptr;
+    hipEvent_t done = nullptr;  // after this slot's last accumulate
+    int cur = 0;
+    int work_slot = 0;
+    int bounces_done = 0;
+  };
+  std::vector<FrameSlot> slots;
+  int frames_in_flight = 8;
+  int active_slot = -1;          // slot of the frame being built by ptc_trace_begin/bounce/end
+  int last_slot = 0;             // slot of the most recent finished frame
+  hipEvent_t order_event = nullptr;  // last accumulate enqueued (accumulates run in iteration order)
+  bool order_valid = false;
+  hipEvent_t main_event = nullptr;   // last main-stream consumer that read the framebuffers asynchronously
+  bool main_valid = false;
   DFrame fb{};
   float4* den_a = nullptr;
   float4* den_b = nullptr;
   const float4* result = nullptr;
   float* pack_buf = nullptr;     // 3 floats / pixel staging for downloads
   uint32_t* rgba_buf = nullptr;  // staging for host presents
-  DeviceCounters* counters = nullptr;
+  DeviceCounters* misc_counters = nullptr;  // flags of kernels outside the frame loop (ptc_intersect_rays)
 
   int iteration = 0;
   int max_iterations = 1;
@@ -68,17 +88,15 @@ struct ptc_ctx {
   ptc_denoiser_params den{10, 0.45f, 0.30f, 0.25f};
   DCamera cam{};
   bool have_cam = false;
-  bool in_frame = false;
   uint64_t frames = 0;
 
-  int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse (default); 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
+  int trace_variant = 2;  // 2: persistent lanes over the two-wide records (default); 3: over the four-wide collapse; 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
   struct Segment {
     bool mesh;
     uint32_t begin, end;  // object range (mesh: one object)
   };
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
   uint32_t traverse_waves = 4096;
-  int work_slot = 0;
 
   // measurement
   bool time_trace = false;
@@ -87,6 +105,7 @@ struct ptc_ctx {
     hipEvent_t start, stop;
     int bounce;
   };
+  bool staging() const { return slots.size() > 1; }
   std::vector<TimedLaunch> timed;        // recorded, not yet read
   std::vector<hipEvent_t> free_events;
   double trace_ms[kMaxBounces] = {};
@@ -219,6 +238,28 @@ uint32_t bvh_depth_of(const ptc_bvh_node* nodes, uint32_t count)
   return deepest;
 }
 
+
+// wait (host-side) until every frame in flight has been folded into the framebuffers
+int sync_frames(ptc_ctx* ctx)
+{
+  for (auto& sl : ctx->slots)
+    if (sl.stream) HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->order_valid = false;
+  ctx->main_valid = false;
+  return PTC_OK;
+}
+
+void free_slots(ptc_ctx* ctx)
+{
+  for (auto& sl : ctx->slots) {
+    if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
+  ctx->slots.clear();
+  ctx->active_slot = -1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,8 +316,11 @@ int ptc_create(const ptc_config* config, ptc_ctx** out)
   ctx->stream = ctx->own_stream;
   void* p = nullptr;
   if (hipMalloc(&p, sizeof(DeviceCounters)) != hipSuccess) return bail(fail(ctx, PTC_ERR_OOM, "hipMalloc(counters) failed"));
-  ctx->counters = static_cast<DeviceCounters*>(p);
-  if (hipMemset(ctx->counters, 0, sizeof(DeviceCounters)) != hipSuccess) return bail(fail(ctx, PTC_ERR_HIP, "hipMemset failed"));
+  ctx->misc_counters = static_cast<DeviceCounters*>(p);
+  if (hipMemset(ctx->misc_counters, 0, sizeof(DeviceCounters)) != hipSuccess) return bail(fail(ctx, PTC_ERR_HIP, "hipMemset failed"));
+  if (hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(ctx, PTC_ERR_HIP, "hipEventCreate failed"));
   *out = ctx;
   return PTC_OK;
 }
@@ -285,7 +329,10 @@ void ptc_destroy(ptc_ctx* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  for (auto& sl : ctx->slots)
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  free_slots(ctx);
   free_pool(ctx->scene_allocs);
   free_pool(ctx->frame_allocs);
   for (auto& tl : ctx->timed) {
@@ -293,7 +340,9 @@ void ptc_destroy(ptc_ctx* ctx)
     (void)hipEventDestroy(tl.stop);
   }
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
-  if (ctx->counters) (void)hipFree(ctx->counters);
+  if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
+  if (ctx->main_event) (void)hipEventDestroy(ctx->main_event);
+  if (ctx->misc_counters) (void)hipFree(ctx->misc_counters);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -302,8 +351,9 @@ int ptc_set_stream(ptc_ctx* ctx, void* hip_stream)
 {
   if (!ctx) return PTC_ERR_INVALID;
   if (int rc = bind_device(ctx)) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_frames(ctx)) return rc;
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  if (ctx->slots.size() == 1) ctx->slots[0].stream = ctx->stream;  // one frame in flight: trace on the caller's stream
   return PTC_OK;
 }
 
@@ -423,22 +473,44 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   if (!ctx || width < 2u || height < 2u) return fail(ctx, PTC_ERR_INVALID, "resolution must be at least 2x2");
   if ((uint64_t)width * height > 0x7fffffffull) return fail(ctx, PTC_ERR_INVALID, "too many pixels");
   if (int rc = bind_device(ctx)) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_frames(ctx)) return rc;
+  free_slots(ctx);
   free_pool(ctx->frame_allocs);
   const size_t P = (size_t)width * height;
   auto& pool = ctx->frame_allocs;
-  for (int k = 0; k < 2; ++k) {
-    if (int rc = dev_alloc(ctx, pool, &ctx->paths[k].o4, P)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &ctx->paths[k].d4, P)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &ctx->paths[k].t4, P)) return rc;
-  }
-  if (int rc = dev_alloc(ctx, pool, &ctx->hits.tp, P)) return rc;
-  if (int rc = dev_alloc(ctx, pool, &ctx->hits.nm, P)) return rc;
   const size_t chunks = (P + kChunk - 1) / kChunk;
-  if (int rc = dev_alloc(ctx, pool, &ctx->chunk_counts, chunks)) return rc;
-  if (int rc = dev_alloc(ctx, pool, &ctx->chunk_offsets, chunks)) return rc;
+  const int F = std::max(1, ctx->frames_in_flight);
+  ctx->slots.resize((size_t)F);
   if (int rc = dev_alloc(ctx, pool, &ctx->fb.color4, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->fb.nd4, P)) return rc;
+  for (int f = 0; f < F; ++f) {
+    auto& sl = ctx->slots[(size_t)f];
+    if (F == 1) {
+      sl.stream = ctx->stream;
+      sl.own_stream = false;
+    } else {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+      sl.own_stream = true;
+    }
+    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].o4, P)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].d4, P)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].t4, P)) return rc;
+    }
+    if (int rc = dev_alloc(ctx, pool, &sl.hits.tp, P)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, P)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, chunks)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, chunks)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.counters, 1)) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(sl.counters, 0, sizeof(DeviceCounters), ctx->stream));
+    if (F == 1) {
+      sl.stage = ctx->fb;  // shade accumulates straight into the framebuffers
+    } else {
+      if (int rc = dev_alloc(ctx, pool, &sl.stage.color4, P)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.stage.nd4, P)) return rc;
+    }
+  }
   if (int rc = dev_alloc(ctx, pool, &ctx->den_a, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->den_b, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->pack_buf, P * 3u)) return rc;
@@ -455,7 +527,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   ctx->pix_capacity = (uint32_t)P;
   ctx->result = ctx->fb.color4;
   ctx->have_cam = false;
-  ctx->in_frame = false;
+  ctx->last_slot = 0;
   return ptc_restart(ctx);
 }
 
@@ -463,6 +535,8 @@ int ptc_set_rows(ptc_ctx* ctx, uint32_t row_begin, uint32_t row_end)
 {
   if (!ctx || !ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
   if (row_begin >= row_end || row_end > ctx->height) return fail(ctx, PTC_ERR_INVALID, "bad row range");
+  if (int rc = bind_device(ctx)) return rc;
+  if (int rc = sync_frames(ctx)) return rc;
   ctx->pix_begin = row_begin * ctx->width;
   ctx->pix_count = (row_end - row_begin) * ctx->width;
   return ptc_restart(ctx);
@@ -521,6 +595,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->traverse_waves = (uint32_t)value;
     return PTC_OK;
   }
+  if (std::strcmp(name, "frames_in_flight") == 0) {
+    if (value < 1 || value > 16) return fail(ctx, PTC_ERR_INVALID, "frames_in_flight must be in [1,16]");
+    if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set frames_in_flight before ptc_resize");
+    ctx->frames_in_flight = value;
+    return PTC_OK;
+  }
   return fail(ctx, PTC_ERR_INVALID, std::string("unknown parameter ") + name);
 }
 
@@ -543,26 +623,34 @@ int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
 {
   if (int rc = frame_ready(ctx)) return rc;
   if (!camera) return fail(ctx, PTC_ERR_INVALID, "camera is NULL");
-  if (ctx->in_frame) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_end missing");
+  if (ctx->active_slot >= 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_end missing");
   ctx->cam = make_camera(*camera, ctx->width, ctx->height);
   ctx->have_cam = true;
-  ctx->cur = 0;
-  ctx->work_slot = 0;
-  launch_raygen(ctx->stream, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count, ctx->paths[0], ctx->counters);
+  const int f = ctx->iteration % (int)ctx->slots.size();
+  auto& sl = ctx->slots[(size_t)f];
+  // the slot's previous frame has been enqueued on the same stream, so its buffers are free in stream order;
+  // a main-stream consumer that still reads the framebuffers (denoise) must finish before anything is folded in
+  if (ctx->main_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
+  sl.cur = 0;
+  sl.work_slot = 0;
+  sl.bounces_done = 0;
+  launch_raygen(sl.stream, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count, sl.paths[0], sl.counters);
   if (int rc = check_last(ctx, "raygen")) return rc;
-  ctx->in_frame = true;
+  ctx->active_slot = f;
   return PTC_OK;
 }
 
 int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
 {
   if (int rc = frame_ready(ctx)) return rc;
-  if (!ctx->in_frame) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
   if (bounce < 0 || bounce >= ctx->max_bounces) return fail(ctx, PTC_ERR_INVALID, "bounce out of range");
+  auto& sl = ctx->slots[(size_t)ctx->active_slot];
   const bool last = bounce == ctx->max_bounces - 1;
-  DPaths in = ctx->paths[ctx->cur], out = ctx->paths[ctx->cur ^ 1];
-  ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
-  if (ctx->time_trace) {
+  DPaths in = sl.paths[sl.cur], out = sl.paths[sl.cur ^ 1];
+  // HIP events around each launch of the dominant (closest-hit) kernel, on the stream it runs on
+  auto timed_begin = [&](ptc_ctx::TimedLaunch& tl) -> int {
+    if (!ctx->time_trace) return PTC_OK;
     for (hipEvent_t* e : {&tl.start, &tl.stop}) {
       if (!ctx->free_events.empty()) {
         *e = ctx->free_events.back();
@@ -571,44 +659,67 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         HIP_TRY(ctx, hipEventCreate(e));
       }
     }
-    HIP_TRY(ctx, hipEventRecord(tl.start, ctx->stream));
-  }
+    HIP_TRY(ctx, hipEventRecord(tl.start, sl.stream));
+    return PTC_OK;
+  };
+  auto timed_end = [&](ptc_ctx::TimedLaunch& tl) -> int {
+    if (!ctx->time_trace) return PTC_OK;
+    HIP_TRY(ctx, hipEventRecord(tl.stop, sl.stream));
+    ctx->timed.push_back(tl);
+    return PTC_OK;
+  };
   if (ctx->trace_variant >= 2) {
     // closest hit = the object list walked as segments (see launch_spheres / launch_traverse)
     for (size_t k = 0; k < ctx->segments.size(); ++k) {
       const auto& seg = ctx->segments[k];
       const bool first = k == 0, final_seg = k + 1 == ctx->segments.size();
       if (seg.mesh) {
-        if (ctx->work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
-          HIP_TRY(ctx, hipMemsetAsync(&ctx->counters->work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, ctx->stream));
-          ctx->work_slot = 0;
+        if (sl.work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
+          HIP_TRY(ctx, hipMemsetAsync(&sl.counters->work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, sl.stream));
+          sl.work_slot = 0;
         }
-        launch_traverse(ctx->stream, ctx->scene, seg.begin, first, in, ctx->hits, bounce, ctx->work_slot++, ctx->counters,
+        ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
+        if (int rc = timed_begin(tl)) return rc;
+        launch_traverse(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
                         ctx->count_tests, ctx->traverse_waves, ctx->trace_variant);
+        if (int rc = timed_end(tl)) return rc;
       } else {
-        launch_spheres(ctx->stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, ctx->hits, ctx->pix_count, bounce,
-                       ctx->chunk_counts, ctx->counters);
+        launch_spheres(sl.stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
+                       sl.chunk_counts, sl.counters);
       }
     }
   } else {
-    launch_trace(ctx->stream, ctx->scene, in, ctx->hits, ctx->pix_count, bounce, ctx->chunk_counts, ctx->counters,
+    ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
+    if (int rc = timed_begin(tl)) return rc;
+    launch_trace(sl.stream, ctx->scene, in, sl.hits, ctx->pix_count, bounce, sl.chunk_counts, sl.counters,
                  ctx->count_tests, ctx->trace_variant);
+    if (int rc = timed_end(tl)) return rc;
   }
-  if (ctx->time_trace) {
-    HIP_TRY(ctx, hipEventRecord(tl.stop, ctx->stream));
-    ctx->timed.push_back(tl);
-  }
-  launch_scan(ctx->stream, bounce, last, ctx->chunk_counts, ctx->chunk_offsets, ctx->counters);
-  launch_shade(ctx->stream, ctx->scene, in, out, ctx->hits, ctx->pix_count, (uint32_t)ctx->iteration, bounce, last,
-               slot_base_dev, ctx->chunk_offsets, ctx->fb, ctx->pix_begin, ctx->counters);
-  ctx->cur ^= 1;
+  launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters);
+  launch_shade(sl.stream, ctx->scene, in, out, sl.hits, ctx->pix_count, (uint32_t)ctx->iteration,
+               ctx->staging() ? 0u : (uint32_t)ctx->iteration, bounce, last, slot_base_dev, sl.chunk_offsets, sl.stage,
+               ctx->pix_begin, sl.counters);
+  sl.cur ^= 1;
+  sl.bounces_done = bounce + 1;
   return check_last(ctx, "bounce");
 }
 
 int ptc_trace_end(ptc_ctx* ctx)
 {
-  if (!ctx || !ctx->in_frame) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
-  ctx->in_frame = false;
+  if (!ctx || ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (int rc = bind_device(ctx)) return rc;
+  auto& sl = ctx->slots[(size_t)ctx->active_slot];
+  if (ctx->staging()) {
+    // fold this sample in after the previous iteration's fold (running means do not commute)
+    if (ctx->order_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->order_event, 0));
+    launch_accumulate(sl.stream, (uint32_t)ctx->iteration, sl.stage, ctx->fb, ctx->pix_count);
+    if (int rc = check_last(ctx, "accumulate")) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->order_event, sl.stream));
+    ctx->order_valid = true;
+  }
+  HIP_TRY(ctx, hipEventRecord(sl.done, sl.stream));
+  ctx->last_slot = ctx->active_slot;
+  ctx->active_slot = -1;
   ++ctx->iteration;
   ++ctx->frames;
   ctx->result = ctx->fb.color4;  // path_tracer.cu:476
@@ -617,8 +728,9 @@ int ptc_trace_end(ptc_ctx* ctx)
 
 int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr)
 {
-  if (!ctx || !dev_ptr || bounce < 0 || bounce > (int)kMaxBounces) return PTC_ERR_INVALID;
-  *dev_ptr = &ctx->counters->live[bounce];
+  if (!ctx || !dev_ptr || bounce < 0 || bounce > (int)kMaxBounces || ctx->slots.empty()) return PTC_ERR_INVALID;
+  const auto& sl = ctx->slots[(size_t)(ctx->active_slot >= 0 ? ctx->active_slot : ctx->last_slot)];
+  *dev_ptr = &sl.counters->live[bounce];
   return PTC_OK;
 }
 
@@ -631,11 +743,21 @@ int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
     return PTC_OK;
   }
   if (ctx->method == PTC_METHOD_MEGAKERNEL) {
+    // one kernel per sample, accumulating in place: frames are serialised on slot 0's stream
+    if (ctx->staging())
+      if (int rc = sync_frames(ctx)) return rc;
+    auto& sl = ctx->slots[0];
     ctx->cam = make_camera(*camera, ctx->width, ctx->height);
     ctx->have_cam = true;
-    launch_megakernel(ctx->stream, ctx->scene, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count,
-                      ctx->max_bounces, ctx->fb, ctx->counters);
+    launch_megakernel(sl.stream, ctx->scene, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count,
+                      ctx->max_bounces, ctx->fb, sl.counters);
     if (int rc = check_last(ctx, "megakernel")) return rc;
+    HIP_TRY(ctx, hipEventRecord(sl.done, sl.stream));
+    if (ctx->staging()) {
+      HIP_TRY(ctx, hipEventRecord(ctx->order_event, sl.stream));
+      ctx->order_valid = true;
+    }
+    ctx->last_slot = 0;
     ++ctx->iteration;
     ++ctx->frames;
     ctx->result = ctx->fb.color4;
@@ -644,7 +766,7 @@ int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
   if (int rc = ptc_trace_begin(ctx, camera)) return rc;
   for (int b = 0; b < ctx->max_bounces; ++b)
     if (int rc = ptc_trace_bounce(ctx, b, nullptr)) {
-      ctx->in_frame = false;
+      ctx->active_slot = -1;
       return rc;
     }
   return ptc_trace_end(ctx);
@@ -655,6 +777,10 @@ int ptc_denoise(ptc_ctx* ctx)
   if (int rc = frame_ready(ctx)) return rc;
   if (!ctx->have_cam) return fail(ctx, PTC_ERR_INVALID, "denoise needs a traced frame (it reuses the last camera)");
   if (ctx->pix_count != ctx->width * ctx->height) return fail(ctx, PTC_ERR_INVALID, "denoise needs the full frame in one context");
+  // every sample must be folded in before the framebuffers are read (stream order, no host sync)
+  if (ctx->order_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_event, 0));
+  else if (!ctx->slots.empty() && ctx->slots[(size_t)ctx->last_slot].stream != ctx->stream)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slots[(size_t)ctx->last_slot].done, 0));
   const DDenoise prm{ctx->den.color_weight, ctx->den.normal_weight, ctx->den.position_weight};
   // edge_avoiding_a_trous_denoiser.cu:102-108: (color, back, front) <- (back, front, back) after each pass
   const float4* color = ctx->fb.color4;
@@ -670,7 +796,10 @@ int ptc_denoise(ptc_ctx* ctx)
     front = new_front;
   }
   ctx->result = front;
-  return check_last(ctx, "denoise");
+  if (int rc = check_last(ctx, "denoise")) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->main_event, ctx->stream));
+  ctx->main_valid = true;
+  return PTC_OK;
 }
 
 int ptc_present_rgba8(ptc_ctx* ctx, void* dst, int dst_is_device, int display_type)
@@ -687,6 +816,7 @@ int ptc_present_rgba8(ptc_ctx* ctx, void* dst, int dst_is_device, int display_ty
   case PTC_DISPLAY_DEPTH: src = ctx->fb.nd4; mode = 2; break;
   default: return fail(ctx, PTC_ERR_INVALID, "unknown display type");
   }
+  if (int rc = sync_frames(ctx)) return rc;
   uint32_t* out = dst_is_device ? static_cast<uint32_t*>(dst) : ctx->rgba_buf;
   launch_preview(ctx->stream, src, ctx->pix_count, mode, out);
   if (int rc = check_last(ctx, "preview")) return rc;
@@ -711,6 +841,7 @@ int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device)
   case PTC_BUF_FINAL: src = ctx->result; break;
   default: return fail(ctx, PTC_ERR_INVALID, "unknown buffer");
   }
+  if (int rc = sync_frames(ctx)) return rc;
   float* out = dst_is_device ? static_cast<float*>(dst) : ctx->pack_buf;
   launch_pack(ctx->stream, src, ctx->pix_count, sel, out);
   if (int rc = check_last(ctx, "pack")) return rc;
@@ -723,26 +854,34 @@ int ptc_synchronize(ptc_ctx* ctx)
 {
   if (!ctx) return PTC_ERR_INVALID;
   if (int rc = bind_device(ctx)) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return PTC_OK;
+  return sync_frames(ctx);
 }
 
 int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
 {
   if (!ctx || !out) return PTC_ERR_INVALID;
   if (int rc = bind_device(ctx)) return rc;
-  DeviceCounters host;
-  HIP_TRY(ctx, hipMemcpyAsync(&host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_frames(ctx)) return rc;
   std::memset(out, 0, sizeof *out);
-  out->rays_total = host.rays_total;
+  uint32_t flags = 0;
+  const size_t head = offsetof(DeviceCounters, work);  // everything but the fetch cursors
+  std::vector<char> buf(sizeof(DeviceCounters));
+  for (size_t f = 0; f < ctx->slots.size(); ++f) {
+    HIP_TRY(ctx, hipMemcpy(buf.data(), ctx->slots[f].counters, head, hipMemcpyDeviceToHost));
+    const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
+    out->rays_total += host.rays_total;
+    flags |= host.flags;
+    if ((int)f == ctx->last_slot)
+      for (int i = 0; i < PTC_MAX_BOUNCES_CAP; ++i) out->last_live[i] = i < ctx->max_bounces ? host.live[i] : 0u;
+  }
+  HIP_TRY(ctx, hipMemcpy(buf.data(), ctx->misc_counters, head, hipMemcpyDeviceToHost));
+  flags |= reinterpret_cast<const DeviceCounters*>(buf.data())->flags;
   out->frames = ctx->frames;
-  for (int i = 0; i < PTC_MAX_BOUNCES_CAP; ++i) out->last_live[i] = i < ctx->max_bounces ? host.live[i] : 0u;
   out->bvh_node_count = ctx->bvh_nodes;
   out->bvh_max_depth = ctx->bvh_depth;
   out->triangle_count = ctx->triangles;
   out->stack_capacity = kStackDepth;
-  if (host.flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow during rendering");
+  if (flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow during rendering");
   return PTC_OK;
 }
 
@@ -773,13 +912,13 @@ int ptc_reset_profile(ptc_ctx* ctx)
 {
   if (!ctx) return PTC_ERR_INVALID;
   if (int rc = bind_device(ctx)) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_frames(ctx)) return rc;
   if (int rc = drain_timed(ctx)) return rc;
   std::memset(ctx->trace_ms, 0, sizeof ctx->trace_ms);
   std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
-  const size_t off = offsetof(DeviceCounters, paths);
-  HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->counters) + off, 0, sizeof(DeviceCounters) - off, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t off = offsetof(DeviceCounters, paths), end = offsetof(DeviceCounters, work);
+  for (auto& sl : ctx->slots)
+    HIP_TRY(ctx, hipMemset(reinterpret_cast<char*>(sl.counters) + off, 0, end - off));
   return PTC_OK;
 }
 
@@ -787,20 +926,26 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
 {
   if (!ctx || !out) return PTC_ERR_INVALID;
   if (int rc = bind_device(ctx)) return rc;
-  DeviceCounters host;
-  HIP_TRY(ctx, hipMemcpyAsync(&host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = sync_frames(ctx)) return rc;
   if (int rc = drain_timed(ctx)) return rc;
   std::memset(out, 0, sizeof *out);
+  const size_t head = offsetof(DeviceCounters, work);
+  std::vector<char> buf(sizeof(DeviceCounters));
+  for (auto& sl : ctx->slots) {
+    HIP_TRY(ctx, hipMemcpy(buf.data(), sl.counters, head, hipMemcpyDeviceToHost));
+    const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
+    for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {
+      out->paths[b] += host.paths[b];
+      out->box_tests[b] += host.box_tests[b];
+      out->tri_tests[b] += host.tri_tests[b];
+      out->max_box_tests[b] = std::max(out->max_box_tests[b], host.max_box_tests[b]);
+      out->max_ray_cycles[b] = std::max(out->max_ray_cycles[b], host.max_ray_cycles[b]);
+      out->max_wave_cycles[b] = std::max(out->max_wave_cycles[b], host.max_wave_cycles[b]);
+    }
+  }
   for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {
-    out->paths[b] = host.paths[b];
-    out->box_tests[b] = host.box_tests[b];
-    out->tri_tests[b] = host.tri_tests[b];
     out->trace_ms[b] = ctx->trace_ms[b];
     out->trace_launches[b] = ctx->trace_launches[b];
-    out->max_box_tests[b] = host.max_box_tests[b];
-    out->max_ray_cycles[b] = host.max_ray_cycles[b];
-    out->max_wave_cycles[b] = host.max_wave_cycles[b];
   }
   return PTC_OK;
 }
@@ -832,7 +977,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   hipError_t e = hipMemcpyAsync(ro, ho.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(rd, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->counters, ctx->trace_variant == 0 ? 0 : 1);
+    launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->misc_counters, ctx->trace_variant == 0 ? 0 : 1);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(tp.data(), hits.tp, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);

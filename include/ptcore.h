@@ -179,6 +179,9 @@ int ptc_set_method(ptc_ctx* ctx, int method);                       /* PathTrace
 int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces);             /* static max_bounces = 50, path_tracer.cu:27 */
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* PathTracer::atrous_denoiser */
 /* Closest-hit kernel variant:
+ *   3           = like 2 over the tree collapsed to four children per 128-byte node; box decisions only
+ *                 conservative, every candidate triangle re-checked against its parent's box with the
+ *                 reference's arithmetic (sufficient: see DESIGN.md "nesting")
  *   2 (default) = culled near-first traversal over the wide node layout, persistent wavefronts whose lanes
  *                 fetch the next ray as soon as their own is finished; objects walked as sphere / mesh segments
  *   1           = the same traversal, one wavefront per 64 fixed paths
@@ -186,8 +189,11 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
  *                 t culling)
  * All return the same hits (same box decisions, same tie rule); 0 and 1 exist to cross-check 2 on the GPU. */
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
-/* Tuning knobs (speed only, never results).  Known names: "traverse_waves" = persistent wavefronts launched per
- * traversal segment (default 4096; set before ptc_upload_scene). */
+/* Tuning knobs (speed only, never results).  Known names:
+ *   "traverse_waves"   persistent wavefronts launched per traversal segment (default 4096; before ptc_upload_scene)
+ *   "frames_in_flight" consecutive iterations traced concurrently on separate streams, folded into the
+ *                      framebuffer in iteration order (default 8; 1 = strictly serial on the context's
+ *                      stream; set before ptc_resize) */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
 /* ---- the hot path ---- */
