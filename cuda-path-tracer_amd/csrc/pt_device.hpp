@@ -73,6 +73,7 @@ struct DScene {
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
   uint32_t bvh4_root;
+  uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle
   float root_min[3];               // box of the root (tested before descending, like any inner node)
   float root_max[3];
   uint32_t root_ref;               // record 0, or kLeafBit for a single-triangle mesh
@@ -118,7 +119,7 @@ struct DFrame {
 struct DeviceCounters {
   uint32_t live[kMaxBounces + 1];  // live paths entering bounce b of the current frame
   uint32_t flags;
-  uint32_t pad;
+  uint32_t slow_count;             // rays handed to k_slow_rays by the running traversal launch
   unsigned long long rays_total;
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
@@ -149,7 +150,11 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
                     DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
                     DeviceCounters* counters);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant);
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,
+                     uint32_t* slow_list);
+// rays with a degenerate direction that the persistent kernels set aside: reference-order traversal
+void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
+                      const uint32_t* slow_list, DeviceCounters* counters);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

@@ -1180,6 +1180,297 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// variant 4: persistent traversal over the two-wide records, conservative FMA slabs, exact acceptance
+// ------------------------------------------------------------------------------------------------
+// Same contract as variant 3 (conservative traversal + the reference's own box test on the parent of every
+// candidate triangle), on the 64-byte two-child records.  Because the slab tests here only have to be
+// conservative they use fused multiply-adds against a per-ray precomputed origin term and a per-ray
+// absolute tolerance that covers the cancellation error of that form; leaf children are tested in the
+// same step as their parent, so a lane does one node per loop iteration.
+template <bool kCount, bool kFirst>
+__global__ __launch_bounds__(kWave) void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
+                                                     int work_slot, DeviceCounters* counters, uint32_t* slow_list)
+{
+  __shared__ uint32_t s_stack[kWideStack * kWave];
+  uint32_t* stack = s_stack + threadIdx.x;
+  const uint32_t n = counters->live[bounce];
+  if (n == 0u) return;
+  const DObject* obj = sc.objects + obj_index;
+  const uint32_t mat = sc.object_material[obj_index];
+  const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
+  if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
+  RayFeed feed;
+  feed.init(n, &counters->work[work_slot][0][0]);
+  uint32_t priv_next = 0u, priv_end = 0u;
+
+  bool active = false;
+  bool pending = false;  // traversal finished, result not yet written (done in batches, just before a refill)
+  uint32_t slot = 0u, cur = 0u, flags = 0u;
+  int sp = 0, best_k = -1;
+  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);  // -o/d minus / plus the per-axis error bound of the FMA slab form
+  bool neg_x = false, neg_y = false, neg_z = false;
+  float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
+  Tally tally;
+  uint32_t ray_boxes = 0u;
+
+  for (;;) {
+    const uint64_t idle_mask = __ballot(!active);
+    const uint32_t idle = (uint32_t)__popcll(idle_mask);
+    const bool more = priv_next < priv_end || !feed.exhausted();
+    if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
+      // results of the rays that finished since the last refill, all at once (the winner's reachability test
+      // costs ~150 instructions: paid per batch of lanes, not per loop iteration)
+      if (pending) {
+      if (best_k >= 0) {
+          // The winner is the closest of ALL candidates; it is the reference's answer iff the reference can reach
+          // it, i.e. iff its parent's box passes the reference's own test (nesting).  If not (a ray grazing
+          // that box within rounding), the ray is redone in the reference's order by k_slow_rays.
+          const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
+          const f3 od = normalize(xform_vector(obj->inv_m, rd));
+          float en, ef;
+          if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef), 0)) {
+            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+            best_k = -2;
+          }
+        }
+        if (best_k >= 0) {
+          const float4 tc = tris[3u * (size_t)best_k + 2u];
+          const f3 outward = mk3(tc.y, tc.z, tc.w);
+          const f3 p = ro + rd * best_t;
+          const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
+          const f3 nn = side == 0u ? outward : -outward;
+          hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
+          hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+        } else if (kFirst && best_k == -1) {
+          hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+        }
+        if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
+        pending = false;
+      }
+      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
+      const uint32_t mine = priv_next + rank_below(idle_mask);
+      const uint32_t range_end = priv_end;
+      priv_next = min(priv_end, priv_next + idle);
+      if (!active && mine < range_end) {
+        slot = mine;
+        const float4 o4 = paths.o4[slot];
+        const float4 d4 = paths.d4[slot];
+        ro = xyz(o4);
+        rd = xyz(d4);
+        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
+        float t_in = FLT_MAX;
+        if (!kFirst) {
+          const float carried = hits.tp[slot].x;
+          if (carried >= 0.0f) t_in = carried;
+        }
+        bool go = sc.bvh_node_count != 0u && ray_aabb(ro, rd, ld3(obj->bmin), ld3(obj->bmax));  // path_tracer.cu:84
+        bool wrote = false;
+        if (go) {
+          const f3 v = xform_vector(obj->inv_m, rd);  // inverse_transform_ray, transform.hpp:51-58
+          scale = ieee_sqrt(dot(v, v));
+          const f3 od = v * (1.0f / scale);
+          oo = xform_point(obj->inv_m, ro);
+          inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)), 0)) {
+            // degenerate direction (0/0 in the reference's slab test voids the nesting argument):
+            // set aside for k_slow_rays, which walks the tree in the reference's own order
+            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+            wrote = true;
+            go = false;
+          } else {
+            // Conservative slab form t = fma(b, 1/d, -o/d).  Against the reference's (b - o)/d it is off by at
+            // most a few ulp of |b/d| + |o/d| per axis; that bound (|b| <= the root box) is folded into the
+            // two origin terms so the near side can only move nearer and the far side farther.
+            const f3 oi = mk3(-(oo.x * inv.x), -(oo.y * inv.y), -(oo.z * inv.z));
+            const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
+            const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
+            const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
+            const f3 tol = mk3(1e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
+                               1e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
+                               1e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
+            oin = oi - tol;
+            oif = oi + tol;
+            neg_x = inv.x < 0.0f;
+            neg_y = inv.y < 0.0f;
+            neg_z = inv.z < 0.0f;
+            best_t = t_in;
+            best_k = -1;
+            limit = scale * best_t;
+            cur = sc.root_ref;
+            sp = 0;
+            ray_boxes = 0u;
+          }
+        }
+        if (go) active = true;
+        else if (kFirst && !wrote) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (__ballot(active) == 0ull) {
+      if (priv_next >= priv_end && feed.exhausted()) {
+        if (pending) {
+      if (best_k >= 0) {
+            // The winner is the closest of ALL candidates; it is the reference's answer iff the reference can reach
+            // it, i.e. iff its parent's box passes the reference's own test (nesting).  If not (a ray grazing
+            // that box within rounding), the ray is redone in the reference's order by k_slow_rays.
+            const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
+            const f3 od = normalize(xform_vector(obj->inv_m, rd));
+            float en, ef;
+            if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef), 0)) {
+              slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+              best_k = -2;
+            }
+          }
+          if (best_k >= 0) {
+            const float4 tc = tris[3u * (size_t)best_k + 2u];
+            const f3 outward = mk3(tc.y, tc.z, tc.w);
+            const f3 p = ro + rd * best_t;
+            const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
+            const f3 nn = side == 0u ? outward : -outward;
+            hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
+            hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+          } else if (kFirst && best_k == -1) {
+            hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+          }
+          if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
+          pending = false;
+        }
+        break;
+      }
+      continue;
+    }
+
+    bool done = false;
+    if (active && !(cur & kLeafBit)) {
+      const float4 w0 = sc.wide[4u * (size_t)cur], w1 = sc.wide[4u * (size_t)cur + 1u];
+      const float4 w2 = sc.wide[4u * (size_t)cur + 2u], w3 = sc.wide[4u * (size_t)cur + 3u];
+      const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
+      if (kCount) { tally.boxes += 2u; ray_boxes += 2u; }
+      // conservative slabs: the near / far plane of each axis is picked by the sign of 1/d, one FMA each
+      const float ln = fmaxf(fmaxf(__builtin_fmaf(neg_x ? w0.w : w0.x, inv.x, oin.x),
+                                   __builtin_fmaf(neg_y ? w1.x : w0.y, inv.y, oin.y)),
+                             __builtin_fmaf(neg_z ? w1.y : w0.z, inv.z, oin.z));
+      const float lf = fminf(fminf(__builtin_fmaf(neg_x ? w0.x : w0.w, inv.x, oif.x),
+                                   __builtin_fmaf(neg_y ? w0.y : w1.x, inv.y, oif.y)),
+                             __builtin_fmaf(neg_z ? w0.z : w1.y, inv.z, oif.z));
+      const float rn = fmaxf(fmaxf(__builtin_fmaf(neg_x ? w2.y : w1.z, inv.x, oin.x),
+                                   __builtin_fmaf(neg_y ? w2.z : w1.w, inv.y, oin.y)),
+                             __builtin_fmaf(neg_z ? w2.w : w2.x, inv.z, oin.z));
+      const float rf = fminf(fminf(__builtin_fmaf(neg_x ? w1.z : w2.y, inv.x, oif.x),
+                                   __builtin_fmaf(neg_y ? w1.w : w2.z, inv.y, oif.y)),
+                             __builtin_fmaf(neg_z ? w2.x : w2.w, inv.z, oif.z));
+      // skip a child only if its (already widened) slab interval is empty by a relative margin, lies beyond
+      // the closest hit, or behind the origin (NaN compares false -> visited)
+      const bool go_l = !((lf - ln) < -1e-4f * (fabsf(ln) + fabsf(lf))) && !box_culled(ln, lf, limit);
+      const bool go_r = !((rf - rn) < -1e-4f * (fabsf(rn) + fabsf(rf))) && !box_culled(rn, rf, limit);
+      if (go_l && go_r) {
+        const bool left_first = !(rn < ln);
+        if (sp >= kWideStack) {
+          flags |= kFlagStackOverflow;
+        } else {
+          stack[sp * kWave] = left_first ? rref : lref;
+          ++sp;
+        }
+        cur = left_first ? lref : rref;
+      } else if (go_l || go_r) {
+        cur = go_l ? lref : rref;
+      } else if (sp == 0) {
+        done = true;
+      } else {
+        --sp;
+        cur = stack[sp * kWave];
+      }
+    }
+    if (active && !done && (cur & kLeafBit)) {
+      // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
+      const uint32_t k = cur & ~kLeafBit;
+      const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
+      if (kCount) ++tally.tris;
+      const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
+      const f3 h = cross(rd, e2);
+      const float a = dot(e1, h);
+      if (!(a > -0.0000001f && a < 0.0000001f)) {
+        const float f = 1.0f / a;
+        const f3 sv = ro - p0;
+        const float u = f * dot(sv, h);
+        if (!(u < 0.0f || u > 1.0f)) {
+          const f3 qv = cross(sv, e1);
+          const float w = f * dot(rd, qv);
+          if (!(w < 0.0f || u + w > 1.0f)) {
+            const float t = f * dot(e2, qv);
+            // taken optimistically; whether the reference can reach it is checked once, on the final winner
+            if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
+              best_t = t;
+              best_k = (int)k;
+              limit = scale * t;
+            }
+          }
+        }
+      }
+      if (sp == 0) {
+        done = true;
+      } else {
+        --sp;
+        cur = stack[sp * kWave];
+      }
+    }
+    if (done) {
+      active = false;
+      pending = true;
+    }
+  }
+  if (flags) atomicOr(&counters->flags, flags);
+  if (kCount) {
+    uint32_t b = tally.boxes, t = tally.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off, 64);
+      t += __shfl_down(t, off, 64);
+    }
+    if (threadIdx.x == 0u) {
+      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
+      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+    }
+  }
+}
+
+// Rays a persistent traversal launch set aside (degenerate direction): the reference's own traversal order
+// with its exact box tests (ray_mesh).  One workgroup; the list is almost always empty.
+template <bool kFirst>
+__global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_index, DPaths paths, DHits hits,
+                                                     const uint32_t* slow_list, DeviceCounters* counters)
+{
+  __shared__ uint32_t s_stack[kStackDepth * kWave];
+  const uint32_t count = counters->slow_count;
+  const DObject* obj = sc.objects + obj_index;
+  const uint32_t mat = sc.object_material[obj_index];
+  uint32_t flags = 0u;
+  for (uint32_t i = threadIdx.x; i < count; i += kWave) {
+    const uint32_t slot = slow_list[i];
+    Ray ray = load_ray(paths, slot);
+    if (!kFirst) {
+      const float carried = hits.tp[slot].x;
+      if (carried >= 0.0f) ray.tmax = carried;
+    }
+    Hit rec;
+    rec.t = 0.0f;
+    rec.p = rec.n = mk3(0.f, 0.f, 0.f);
+    rec.mat = 0u;
+    rec.side = 0u;
+    Tally unused;
+    if (ray_mesh<false>(ray, sc, obj, rec, s_stack + threadIdx.x, flags, unused)) {
+      hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
+      hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(mat | (rec.side << 31)));
+    } else if (kFirst) {
+      hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (flags) atomicOr(&counters->flags, flags);
+  __syncthreads();
+  if (threadIdx.x == 0u) counters->slow_count = 0u;
+}
+
 // Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test,
 // path_tracer.cu:78-100), continuing from / handing on the closest hit in the hit record.
 template <bool kFirst, bool kLast>
@@ -1578,10 +1869,27 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
   else
     hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
 }
+void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
+                      const uint32_t* slow_list, DeviceCounters* counters)
+{
+  if (first) hipLaunchKernelGGL((k_slow_rays<true>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters);
+  else hipLaunchKernelGGL((k_slow_rays<false>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters);
+}
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant)
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,
+                     uint32_t* slow_list)
 {
   const dim3 grid(waves), block(kWave);
+  if (variant == 4) {
+    if (count_tests) {
+      if (first) hipLaunchKernelGGL((k_traverse2<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+      else hipLaunchKernelGGL((k_traverse2<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+    } else {
+      if (first) hipLaunchKernelGGL((k_traverse2<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+      else hipLaunchKernelGGL((k_traverse2<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+    }
+    return;
+  }
   if (variant == 3) {
     if (count_tests) {
       if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);

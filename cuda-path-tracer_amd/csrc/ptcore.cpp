@@ -58,6 +58,7 @@ struct ptc_ctx {
     DHits hits{};
     uint32_t* chunk_counts = nullptr;
     uint32_t* chunk_offsets = nullptr;
+    uint32_t* slow_list = nullptr;  // slots of rays set aside for k_slow_rays
     DFrame stage{};
     DeviceCounters* counters = nullptr;
     hipEvent_t done = nullptr;  // after this slot's last accumulate
@@ -90,13 +91,14 @@ struct ptc_ctx {
   bool have_cam = false;
   uint64_t frames = 0;
 
-  int trace_variant = 2;  // 2: persistent lanes over the two-wide records (default); 3: over the four-wide collapse; 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
+  int trace_variant = 4;  // 4: persistent lanes, conservative FMA slabs, exact check of the winner (default); 2, 3: earlier forms; 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
   struct Segment {
     bool mesh;
     uint32_t begin, end;  // object range (mesh: one object)
   };
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
   uint32_t traverse_waves = 4096;
+  uint32_t refill_lanes = 20;
 
   // measurement
   bool time_trace = false;
@@ -434,6 +436,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh4, w4.nodes.data(), w4.nodes.size())) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
   d.bvh4_root = w4.root_ref;
+  d.refill_lanes = ctx->refill_lanes;
   d.spill = nullptr;
   d.spill_stride = ctx->traverse_waves * kWave;
   if (node_count && 3u * w4.depth + 1u > 16u) {  // depth-first over four children: at most 3 pushes per level
@@ -502,6 +505,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, P)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, chunks)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.slow_list, P)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.counters, 1)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(sl.counters, 0, sizeof(DeviceCounters), ctx->stream));
     if (F == 1) {
@@ -581,7 +585,7 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 3) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
+  if (!ctx || variant < 0 || variant > 4) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
   ctx->trace_variant = variant;
   return PTC_OK;
 }
@@ -593,6 +597,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "traverse_waves out of range");
     if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set traverse_waves before ptc_upload_scene");
     ctx->traverse_waves = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "refill_lanes") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, PTC_ERR_INVALID, "refill_lanes must be in [1,64]");
+    ctx->refill_lanes = (uint32_t)value;
+    ctx->scene.refill_lanes = ctx->refill_lanes;
     return PTC_OK;
   }
   if (std::strcmp(name, "frames_in_flight") == 0) {
@@ -681,8 +691,9 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
         if (int rc = timed_begin(tl)) return rc;
         launch_traverse(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
-                        ctx->count_tests, ctx->traverse_waves, ctx->trace_variant);
+                        ctx->count_tests, ctx->traverse_waves, ctx->trace_variant, sl.slow_list);
         if (int rc = timed_end(tl)) return rc;
+        if (ctx->trace_variant == 4) launch_slow_rays(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters);
       } else {
         launch_spheres(sl.stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
                        sl.chunk_counts, sl.counters);

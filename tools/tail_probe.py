@@ -8,6 +8,7 @@ sc=pkg.scenes.heightfield_scene((W,H)); flat=sc.build_scene()
 mesh=list(sc.mesh_map_.values())[0]; flat.bvh,depth=pkg.bvh_from_mesh(mesh)
 for v in variants:
   with pkg.PathTracer(max_bounces=8) as pt:
+    pt.set_param('frames_in_flight', 1)
     pt.create_buffers((W,H), flat); pt.max_iterations=1<<30; pt.set_trace_variant(v)
     for i in range(2): pt.path_trace(sc.camera)
     pt.set_profiling(False, True); pt.reset_profile(); pt.path_trace(sc.camera); pr=pt.profile()
