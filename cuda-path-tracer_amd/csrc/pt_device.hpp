@@ -72,7 +72,9 @@ struct DScene {
   const float4* leaf_parent;       // 2 float4 per triangle
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
+  uint32_t spill_cap;              // entries per thread in `spill`
   uint32_t bvh4_root;
+  uint32_t force_slow;             // test hook: hand EVERY ray to k_slow_rays
   uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle
   float root_min[3];               // box of the root (tested before descending, like any inner node)
   float root_max[3];

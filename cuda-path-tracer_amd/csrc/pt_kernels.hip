@@ -937,7 +937,6 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
 // Rays with a zero / subnormal direction component (0/0 = NaN in the reference's slab test breaks the
 // nesting argument) take the reference-order traversal instead.
 constexpr int kLdsStack = 16;    // (ref, effective near distance) pairs per lane in LDS: 8 KiB per wavefront
-constexpr int kSpillStack = 48;  // further entries per lane in global memory (DScene::spill)
 
 template <bool kCount, bool kFirst>
 __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
@@ -969,7 +968,7 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
   auto push = [&](uint32_t ref, float eff_near) {
     const uint2 e = make_uint2(ref, __float_as_uint(eff_near));
     if (sp < kLdsStack) s_stack[sp * kWave + threadIdx.x] = e;
-    else if (sp < kLdsStack + kSpillStack && sc.spill) sc.spill[(size_t)(sp - kLdsStack) * sc.spill_stride + gid] = e;
+    else if (sp < kLdsStack + (int)sc.spill_cap) sc.spill[(size_t)(sp - kLdsStack) * sc.spill_stride + gid] = e;
     else {
       flags |= kFlagStackOverflow;
       return;
@@ -1188,12 +1187,16 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
 // conservative they use fused multiply-adds against a per-ray precomputed origin term and a per-ray
 // absolute tolerance that covers the cancellation error of that form; leaf children are tested in the
 // same step as their parent, so a lane does one node per loop iteration.
+constexpr int kLds2 = 16;    // traversal stack entries per lane in LDS (4 KiB per wavefront: 8 wavefronts per SIMD fit)
+
 template <bool kCount, bool kFirst>
-__global__ __launch_bounds__(kWave) void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
-                                                     int work_slot, DeviceCounters* counters, uint32_t* slow_list)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
+                 int work_slot, DeviceCounters* counters, uint32_t* slow_list)
 {
-  __shared__ uint32_t s_stack[kWideStack * kWave];
+  __shared__ uint32_t s_stack[kLds2 * kWave];
   uint32_t* stack = s_stack + threadIdx.x;
+  const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
   const uint32_t n = counters->live[bounce];
   if (n == 0u) return;
   const DObject* obj = sc.objects + obj_index;
@@ -1273,7 +1276,7 @@ __global__ __launch_bounds__(kWave) void k_traverse2(DScene sc, uint32_t obj_ind
           const f3 od = v * (1.0f / scale);
           oo = xform_point(obj->inv_m, ro);
           inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)), 0)) {
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow, 0)) {
             // degenerate direction (0/0 in the reference's slab test voids the nesting argument):
             // set aside for k_slow_rays, which walks the tree in the reference's own order
             slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
@@ -1366,11 +1369,15 @@ __global__ __launch_bounds__(kWave) void k_traverse2(DScene sc, uint32_t obj_ind
       const bool go_r = !((rf - rn) < -1e-4f * (fabsf(rn) + fabsf(rf))) && !box_culled(rn, rf, limit);
       if (go_l && go_r) {
         const bool left_first = !(rn < ln);
-        if (sp >= kWideStack) {
-          flags |= kFlagStackOverflow;
-        } else {
-          stack[sp * kWave] = left_first ? rref : lref;
+        const uint32_t later = left_first ? rref : lref;
+        if (sp < kLds2) {
+          stack[sp * kWave] = later;
           ++sp;
+        } else if (sp < kLds2 + (int)sc.spill_cap) {
+          sc.spill[(size_t)(sp - kLds2) * sc.spill_stride + gid].x = later;
+          ++sp;
+        } else {
+          flags |= kFlagStackOverflow;
         }
         cur = left_first ? lref : rref;
       } else if (go_l || go_r) {
@@ -1379,7 +1386,7 @@ __global__ __launch_bounds__(kWave) void k_traverse2(DScene sc, uint32_t obj_ind
         done = true;
       } else {
         --sp;
-        cur = stack[sp * kWave];
+        cur = sp < kLds2 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds2) * sc.spill_stride + gid].x;
       }
     }
     if (active && !done && (cur & kLeafBit)) {
@@ -1412,7 +1419,7 @@ __global__ __launch_bounds__(kWave) void k_traverse2(DScene sc, uint32_t obj_ind
         done = true;
       } else {
         --sp;
-        cur = stack[sp * kWave];
+        cur = sp < kLds2 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds2) * sc.spill_stride + gid].x;
       }
     }
     if (done) {

@@ -97,8 +97,9 @@ struct ptc_ctx {
     uint32_t begin, end;  // object range (mesh: one object)
   };
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
-  uint32_t traverse_waves = 4096;
+  uint32_t traverse_waves = 6144;
   uint32_t refill_lanes = 20;
+  bool force_slow = false;
 
   // measurement
   bool time_trace = false;
@@ -437,10 +438,18 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
   d.bvh4_root = w4.root_ref;
   d.refill_lanes = ctx->refill_lanes;
+  d.force_slow = ctx->force_slow ? 1u : 0u;
   d.spill = nullptr;
   d.spill_stride = ctx->traverse_waves * kWave;
-  if (node_count && 3u * w4.depth + 1u > 16u) {  // depth-first over four children: at most 3 pushes per level
-    if (int rc = dev_alloc(ctx, ctx->scene_allocs, &d.spill, (size_t)48 * d.spill_stride)) return rc;
+  // stack need: one entry per level of the two-wide tree, up to three per level of the four-wide collapse;
+  // whatever exceeds the LDS part (16 entries) goes to this per-thread overflow area
+  d.spill_cap = 0;
+  if (node_count) {
+    const uint32_t need = std::max(depth + 2u, 3u * w4.depth + 2u);
+    if (need > 16u) {
+      d.spill_cap = need - 16u;
+      if (int rc = dev_alloc(ctx, ctx->scene_allocs, &d.spill, (size_t)d.spill_cap * d.spill_stride)) return rc;
+    }
   }
   ctx->bvh4_nodes = w4.node_count;
   ctx->bvh4_depth = w4.depth;
@@ -597,6 +606,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "traverse_waves out of range");
     if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set traverse_waves before ptc_upload_scene");
     ctx->traverse_waves = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "debug_force_slow") == 0) {
+    ctx->scene.force_slow = value ? 1u : 0u;
+    ctx->force_slow = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "refill_lanes") == 0) {

@@ -193,7 +193,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "traverse_waves"   persistent wavefronts launched per traversal segment (default 4096; before ptc_upload_scene)
  *   "frames_in_flight" consecutive iterations traced concurrently on separate streams, folded into the
  *                      framebuffer in iteration order (default 8; 1 = strictly serial on the context's
- *                      stream; set before ptc_resize) */
+ *                      stream; set before ptc_resize)
+ *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
+ *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
 /* ---- the hot path ---- */

@@ -1,0 +1,157 @@
+"""The fast schedules must not change a single bit of the output.
+
+The closest-hit stage exists in five forms (ptc_set_trace_variant): 0 walks the BVH in the reference's own
+order with its exact box tests (path_tracer.cu:36-76); 1-4 change only the schedule (culling, near-first
+order, wide nodes, persistent wavefronts, conservative FMA slabs with an exact check of the winner, several
+frames in flight).  These tests pin every form to form 0 and to the CPU oracle, at small sizes against the
+oracle and at the benchmark size (1920x1080, 1,000,000 triangles) against form 0 and through properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def frames(pkg, scene, flat, w, h, iters, mb, variant=None, fif=None, params=()):
+    with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+        if fif is not None:
+            pt.set_param("frames_in_flight", fif)
+        for k, v in params:
+            pt.set_param(k, v)
+        pt.create_buffers((w, h), flat)
+        if variant is not None:
+            pt.set_trace_variant(variant)
+        pt.max_iterations = iters
+        for _ in range(iters):
+            pt.path_trace(scene.camera)
+        out = {k: pt.download(k) for k in ("color", "normal", "depth")}
+        out["stats"] = pt.stats()
+    return out
+
+
+def same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ("color", "normal", "depth")) and \
+        a["stats"]["rays_total"] == b["stats"]["rays_total"] and a["stats"]["last_live"] == b["stats"]["last_live"]
+
+
+@pytest.fixture(scope="module")
+def small_scenes(pkg):
+    glm = pkg.glmlite
+    bunny = pkg.scenes.cornell_bunny((160, 96), n_lat=20, n_lon=40)
+    mesh = list(bunny.mesh_map_.values())[0]
+    # a third, rotated + non-uniformly scaled glass instance between the others
+    bunny.add_object(mesh, glm.compose([glm.rotate(np.float32(0.6), (0.3, 1.0, 0.2)), glm.scale((0.7, 0.4, 0.9)),
+                                        glm.translate((0.1, 0.2, 0.5))]), "glass")
+    return {"spheres": (pkg.scenes.cornell_spheres((96, 96)), 96, 96),
+            "instances": (bunny, 160, 96),
+            "heightfield": (pkg.scenes.heightfield_scene((160, 96), nx=129, nz=65), 160, 96)}
+
+
+@pytest.mark.parametrize("name", ["spheres", "instances", "heightfield"])
+def test_every_schedule_matches_reference_order_and_oracle(pkg, orc, small_scenes, name):
+    scene, w, h = small_scenes[name]
+    flat = scene.build_scene()
+    base = frames(pkg, scene, flat, w, h, 3, 8, variant=0, fif=1)
+    ref = orc.render_streaming(flat, scene.camera, w, h, 0, 3, 8)
+    assert np.array_equal(base["color"], ref["color"]) and base["stats"]["rays_total"] == ref["rays"]
+    for variant in (1, 2, 3, 4):
+        for fif in (1, 3):
+            got = frames(pkg, scene, flat, w, h, 3, 8, variant=variant, fif=fif)
+            assert same(got, base), (variant, fif)
+
+
+def test_degenerate_ray_fallback_kernel(pkg, small_scenes):
+    """k_slow_rays (rays whose direction has a zero / subnormal component) forced for every ray"""
+    scene, w, h = small_scenes["instances"]
+    flat = scene.build_scene()
+    base = frames(pkg, scene, flat, w, h, 2, 6, variant=0, fif=1)
+    got = frames(pkg, scene, flat, w, h, 2, 6, variant=4, fif=2, params=(("debug_force_slow", 1),))
+    assert same(got, base)
+
+
+def test_axis_aligned_rays(pkg, orc):
+    """A camera whose centre column / row produce direction components of exactly zero after a mirror bounce:
+    axis-aligned metal plane under an axis-aligned view.  Must equal the oracle."""
+    s = pkg.SceneDescription()
+    s.add_material("mirror", pkg.MetalMaterial((0.9, 0.9, 0.9), 0.0))
+    s.add_material("d", pkg.DiffuseMateral((0.5, 0.6, 0.7)))
+    quad = pkg.Mesh(np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2], [-2, 1.5, -2], [2, 1.5, -2], [0, 3, -2]], dtype=np.float32),
+                    np.array([0, 2, 1, 0, 3, 2, 4, 5, 6], dtype=np.uint32))
+    s.add_mesh("quad", quad)
+    s.add_object(quad, pkg.glmlite.identity(), "mirror")
+    s.add_object(pkg.Sphere((0, 0, 0), 0.4), pkg.glmlite.translate((0.0, 0.4, 0.0)), "d")
+    # looking straight down: rotation of -90 degrees about x
+    q = (float(np.cos(-np.pi / 4)), float(np.sin(-np.pi / 4)), 0.0, 0.0)
+    s.camera = pkg.Camera(position=(0.0, 3.0, 0.0), rotation=q, vfov=float(np.radians(60)))
+    flat = s.build_scene()
+    ref = orc.render_streaming(flat, s.camera, 65, 65, 0, 2, 6)
+    for variant in (0, 4):
+        got = frames(pkg, s, flat, 65, 65, 2, 6, variant=variant, fif=2)
+        assert np.array_equal(got["color"], ref["color"]) and got["stats"]["rays_total"] == ref["rays"], variant
+
+
+def test_frames_in_flight_are_folded_in_order(pkg, small_scenes):
+    """Running means do not commute: 8 frames in flight must give the bits of strictly serial execution,
+    also when the framebuffer is read in the middle."""
+    scene, w, h = small_scenes["heightfield"]
+    flat = scene.build_scene()
+    serial = frames(pkg, scene, flat, w, h, 11, 8, variant=4, fif=1)
+    with pkg.PathTracer(max_bounces=8) as pt:
+        pt.set_param("frames_in_flight", 8)
+        pt.create_buffers((w, h), flat)
+        pt.max_iterations = 11
+        for i in range(11):
+            pt.path_trace(scene.camera)
+            if i == 4:
+                mid = pt.download("color")
+        got = {k: pt.download(k) for k in ("color", "normal", "depth")}
+        assert pt.iteration() == 11
+    for k in ("color", "normal", "depth"):
+        assert np.array_equal(got[k], serial[k])
+    five = frames(pkg, scene, flat, w, h, 5, 8, variant=4, fif=1)
+    assert np.array_equal(mid, five["color"])
+
+
+@pytest.fixture(scope="module")
+def big(pkg):
+    scene = pkg.scenes.heightfield_scene((1920, 1080))
+    flat = scene.build_scene()
+    flat.bvh, depth = pkg.bvh_from_mesh(list(scene.mesh_map_.values())[0])
+    return scene, flat, depth
+
+
+def test_benchmark_size_against_reference_order(pkg, big):
+    """1920x1080, 1,000,000 triangles, 8 bounces, 2 iterations: default schedule == reference-order kernel."""
+    scene, flat, depth = big
+    assert len(flat.indices) // 3 == 1_000_000 and len(flat.bvh) == 1_999_999
+    base = frames(pkg, scene, flat, 1920, 1080, 2, 8, variant=0, fif=1)
+    got = frames(pkg, scene, flat, 1920, 1080, 2, 8)
+    assert same(got, base)
+    live = got["stats"]["last_live"]
+    assert live[0] == 1920 * 1080 and all(a >= b for a, b in zip(live, live[1:]))
+    assert np.isfinite(got["color"]).all() and 0.0 <= got["color"].min() and got["color"].max() <= 1.0 + 1e-6
+    # a miss keeps the raygen depth of 1e6 (ray_gen.cu:27); hits are closer
+    assert np.isclose(got["depth"].max(), 1e6) and got["depth"].min() > 0.5
+
+
+def test_benchmark_size_rays_against_oracle(pkg, orc, big):
+    """20,000 random rays into the 1M-triangle scene: hit/miss, t, normal, material identical to the oracle."""
+    scene, flat, depth = big
+    rng = np.random.default_rng(7)
+    n = 20000
+    o = np.stack([rng.uniform(-4.5, 4.5, n), rng.uniform(0.05, 3.0, n), rng.uniform(-2.5, 2.5, n)], axis=1)
+    target = np.stack([rng.uniform(-4, 4, n), rng.uniform(-0.2, 0.9, n), rng.uniform(-2, 2, n)], axis=1)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 1e-4, d, np.finfo(np.float32).max
+    recs, hit = orc.intersect_rays(flat, rays)
+    with pkg.PathTracer() as pt:
+        pt.create_buffers((64, 64), flat)
+        for variant in (0, 1):
+            pt.set_trace_variant(variant)
+            t, nrm, mat, side = pt.intersect_rays(rays)
+            m = hit.astype(bool)
+            assert m.mean() > 0.5
+            assert np.array_equal(t >= 0, m)
+            assert np.array_equal(t[m], recs["t"][m]) and np.array_equal(nrm[m], recs["normal"][m])
+            assert np.array_equal(mat[m], recs["material_id"][m].astype(np.uint32)) and np.array_equal(side[m], recs["side"][m])
