@@ -76,9 +76,10 @@ def main():
     flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)
     bvh_build_s = time.perf_counter() - t0
 
-    # contiguous row bands
-    rows = [(H * r) // world for r in range(world + 1)]
-    row0, row1 = rows[rank], rows[rank + 1]
+    # contiguous row bands (cuda-path-tracer_amd/bands.py)
+    bands = pkg.bands.split_rows(H, world)
+    rows = [b[0] for b in bands] + [H]
+    row0, row1 = bands[rank]
 
     pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
     pt.create_buffers((W, H), flat)

@@ -107,6 +107,8 @@ SIGNATURES = {
     "ptc_trace_bounce": (C.c_int, [_P, C.c_int, _P]),
     "ptc_trace_end": (C.c_int, [_P]),
     "ptc_live_count_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "ptc_copy_live_count": (C.c_int, [_P, C.c_int, _P]),
+    "ptc_read_live_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     "ptc_denoise": (C.c_int, [_P]),
     "ptc_present_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ptc_download": (C.c_int, [_P, C.c_int, _P, C.c_int]),

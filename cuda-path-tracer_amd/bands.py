@@ -1,0 +1,64 @@
+"""Row-band partition of one frame over several GPUs (one process per GPU, torch.distributed / RCCL).
+
+The path shards by pixels: the scene is replicated, each rank traces a contiguous band of image rows with its
+own `PathTracer` (`set_rows`), and the only inter-GPU traffic is the gather of the bands' radiance at present
+time.  Two slot-numbering modes:
+
+  "local"   (default, used by bench.py) every band numbers its compacted paths from 0 at each bounce.  No
+            collective while tracing.  The material RNG is keyed on the slot index (path_tracer.cu:297-301), so
+            the noise pattern differs from the single-GPU image (same distribution).
+  "global"  reproduces the single-GPU image bit for bit: before bounce b every rank learns the live-path
+            counts of all ranks (one all_gather of one uint32 per rank) and offsets its slots by the sum over
+            the lower bands -- exactly the global compacted index the reference would have used.
+"""
+import numpy as np
+
+
+def split_rows(height, world):
+    """Contiguous row ranges [(row_begin, row_end)] for `world` ranks; sizes differ by at most one row."""
+    edges = [(height * r) // world for r in range(world + 1)]
+    return [(edges[r], edges[r + 1]) for r in range(world)]
+
+
+def slot_base_from_counts(counts, rank):
+    """Global slot index of a band's first live path = live paths of all lower bands (stable order)."""
+    return int(np.sum(np.asarray(counts[:rank], dtype=np.uint64)))
+
+
+def assemble(bands):
+    """Stack per-band arrays (rows first) into the full frame, in rank order."""
+    return np.concatenate(list(bands), axis=0)
+
+
+class BandRenderer:
+    """One rank's band of the frame.  `dist` is torch.distributed (initialised) or None for a single rank."""
+
+    def __init__(self, path_tracer, width, height, rank=0, world=1, dist=None, mode="local"):
+        assert mode in ("local", "global")
+        self.pt, self.width, self.height = path_tracer, width, height
+        self.rank, self.world, self.dist, self.mode = rank, world, dist, mode
+        self.rows = split_rows(height, world)[rank]
+        if world > 1:
+            self.pt.set_rows(*self.rows)
+        self._torch = None
+        if mode == "global" and world > 1:
+            import torch
+            self._torch = torch
+            self._mine = torch.zeros(1, dtype=torch.int32, device="cuda")
+            self._all = torch.zeros(world, dtype=torch.int32, device="cuda")
+            self._base = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def trace(self, camera):
+        """One iteration of this band."""
+        if self.mode == "local" or self.world == 1:
+            self.pt.path_trace(camera)
+            return
+        torch = self._torch
+        self.pt.trace_begin(camera)
+        for b in range(self.pt.max_bounces):
+            # live count of this band entering bounce b -> all ranks -> exclusive prefix = slot base
+            self.pt.copy_live_count(b, self._mine.data_ptr())
+            self.dist.all_gather_into_tensor(self._all, self._mine)
+            self._base.copy_(self._all[: self.rank].sum().to(torch.int32).reshape(1) if self.rank else torch.zeros(1, dtype=torch.int32, device="cuda"))
+            self.pt.trace_bounce(b, self._base.data_ptr())
+        self.pt.trace_end()

@@ -759,6 +759,27 @@ int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr)
   return PTC_OK;
 }
 
+int ptc_copy_live_count(ptc_ctx* ctx, int bounce, void* dst_dev)
+{
+  if (!ctx || !dst_dev || bounce < 0 || bounce > (int)kMaxBounces) return PTC_ERR_INVALID;
+  if (ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (int rc = bind_device(ctx)) return rc;
+  auto& sl = ctx->slots[(size_t)ctx->active_slot];
+  HIP_TRY(ctx, hipMemcpyAsync(dst_dev, &sl.counters->live[bounce], sizeof(uint32_t), hipMemcpyDeviceToDevice, sl.stream));
+  return PTC_OK;
+}
+
+int ptc_read_live_count(ptc_ctx* ctx, int bounce, uint32_t* host_out)
+{
+  if (!ctx || !host_out || bounce < 0 || bounce > (int)kMaxBounces) return PTC_ERR_INVALID;
+  if (ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (int rc = bind_device(ctx)) return rc;
+  auto& sl = ctx->slots[(size_t)ctx->active_slot];
+  HIP_TRY(ctx, hipMemcpyAsync(host_out, &sl.counters->live[bounce], sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream));
+  HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+  return PTC_OK;
+}
+
 int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
 {
   if (int rc = frame_ready(ctx)) return rc;

@@ -148,6 +148,15 @@ class PathTracer:
         self._check(self._lib.ptc_live_count_dev(self._ctx, int(bounce), C.byref(p)))
         return p.value
 
+    def copy_live_count(self, bounce, dst_dev):
+        self._check(self._lib.ptc_copy_live_count(self._ctx, int(bounce), C.c_void_p(int(dst_dev))))
+
+    def read_live_count(self, bounce):
+        """Host value of the live-path count entering `bounce` of the frame being built (synchronises its stream)."""
+        v = C.c_uint32(0)
+        self._check(self._lib.ptc_read_live_count(self._ctx, int(bounce), C.byref(v)))
+        return int(v.value)
+
     def synchronize(self):
         self._check(self._lib.ptc_synchronize(self._ctx))
 

@@ -216,6 +216,12 @@ int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera);
 int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev);
 int ptc_trace_end(ptc_ctx* ctx);
 int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr);
+/* Enqueue (on the frame's stream) a copy of that counter into a caller-owned device uint32, e.g. a torch tensor
+ * that is then all-gathered over RCCL.  Only inside ptc_trace_begin .. ptc_trace_end. */
+int ptc_copy_live_count(ptc_ctx* ctx, int bounce, void* dst_dev);
+/* The same value on the host (synchronises the frame's stream): the per-bounce read-back the reference does
+ * after every thrust::stable_partition (path_tracer.cu:457). */
+int ptc_read_live_count(ptc_ctx* ctx, int bounce, uint32_t* host_out);
 
 /* PathTracer::denoise (path_tracer.cu:479-485) */
 int ptc_denoise(ptc_ctx* ctx);

@@ -944,6 +944,8 @@ typedef struct {
   OIntersection* intersections;
   uint64_t iteration;
   uint32_t bounce;
+  uint32_t pix_begin;   /* first pixel of the band (0 for a full frame) */
+  uint32_t slot_base;   /* added to the local slot index before RNG seeding (0 for a full frame) */
   float* fb_color; float* fb_normal; float* fb_depth;
 } StreamCtx;
 
@@ -953,8 +955,9 @@ static void raygen_range(void* p, uint32_t begin, uint32_t end, int tid)
   StreamCtx* c = (StreamCtx*)p;
   const uint32_t W = c->camera.width;
   for (uint32_t index = begin; index < end; ++index) {
-    const uint32_t x = index % W, y = index / W;
-    uint32_t rng = orc_rng_seed(orc_path_seed(index, c->iteration));
+    const uint32_t pixel = c->pix_begin + index;
+    const uint32_t x = pixel % W, y = pixel / W;
+    uint32_t rng = orc_rng_seed(orc_path_seed(pixel, c->iteration));
     const float fx = (float)x + orc_rng_uniform(&rng);
     const float fy = (float)y + orc_rng_uniform(&rng);
     ORay ray;
@@ -964,7 +967,7 @@ static void raygen_range(void* p, uint32_t begin, uint32_t end, int tid)
     c->paths.normal_buffer[index] = vneg(ray.direction);
     c->paths.bounces_left_buffer[index] = 50;
     c->paths.rays[index] = ray;
-    c->paths.pixel_indices[index] = (int)index;
+    c->paths.pixel_indices[index] = (int)pixel;
   }
 }
 
@@ -992,7 +995,7 @@ static void material_range(void* p, uint32_t begin, uint32_t end, int tid)
   (void)tid;
   StreamCtx* c = (StreamCtx*)p;
   for (uint32_t index = begin; index < end; ++index) {
-    uint32_t rng = orc_rng_seed(orc_path_seed(index, c->iteration));
+    uint32_t rng = orc_rng_seed(orc_path_seed(c->slot_base + index, c->iteration));
     orc_rng_discard(&rng, c->bounce);
     const OIntersection isect = c->intersections[index];
     if (isect.t < 0) {
@@ -1012,7 +1015,7 @@ static void gather_range(void* p, uint32_t begin, uint32_t end, int tid)
   (void)tid;
   StreamCtx* c = (StreamCtx*)p;
   for (uint32_t index = begin; index < end; ++index) {
-    const int pixel_index = c->paths.pixel_indices[index];
+    const int pixel_index = c->paths.pixel_indices[index] - (int)c->pix_begin;
     final_gather(c->iteration, c->paths.color_buffer[index], c->paths.normal_buffer[index],
                  c->paths.depth_buffer[index], c->fb_color + 3 * (size_t)pixel_index,
                  c->fb_normal + 3 * (size_t)pixel_index, c->fb_depth + pixel_index);
@@ -1091,6 +1094,44 @@ uint64_t orc_render_streaming(const OScene* scene, const OCamera* cam, uint32_t 
     }
     parallel_for(pixels_count, nthreads, gather_range, &c);
   }
+  free(c.intersections);
+  paths_free(&tmp);
+  paths_free(&c.paths);
+  return rays;
+}
+
+uint64_t orc_render_streaming_band(const OScene* scene, const OCamera* cam, uint32_t w, uint32_t h, uint32_t row0,
+                                   uint32_t row1, uint32_t iteration, uint32_t max_bounces, float* fb_color,
+                                   float* fb_normal, float* fb_depth, uint32_t* live_counts,
+                                   orc_exchange_fn exchange, void* user, int nthreads)
+{
+  const uint32_t pixels_count = (row1 - row0) * w;
+  StreamCtx c;
+  memset(&c, 0, sizeof c);
+  c.scene = scene;
+  orc_to_gpu_camera(cam, w, h, &c.camera);
+  paths_alloc(&c.paths, pixels_count);
+  OPaths tmp;
+  paths_alloc(&tmp, pixels_count);
+  c.intersections = (OIntersection*)malloc(sizeof(OIntersection) * pixels_count);
+  c.fb_color = fb_color; c.fb_normal = fb_normal; c.fb_depth = fb_depth;
+  c.iteration = iteration;
+  c.pix_begin = row0 * w;
+  uint64_t rays = 0;
+  parallel_for(pixels_count, nthreads, raygen_range, &c);
+  uint32_t paths_count = pixels_count;
+  if (live_counts) memset(live_counts, 0, sizeof(uint32_t) * max_bounces);
+  for (uint32_t i = 0; i < max_bounces; ++i) {
+    /* every band takes part in every exchange, also with zero live paths */
+    c.slot_base = exchange ? exchange(user, i, paths_count) : (i == 0 ? c.pix_begin : 0u);
+    if (live_counts) live_counts[i] = paths_count;
+    rays += paths_count;
+    c.bounce = i;
+    parallel_for(paths_count, nthreads, intersection_range, &c);
+    parallel_for(paths_count, nthreads, material_range, &c);
+    paths_count = stable_partition_paths(&c.paths, &tmp, paths_count);
+  }
+  parallel_for(pixels_count, nthreads, gather_range, &c);
   free(c.intersections);
   paths_free(&tmp);
   paths_free(&c.paths);

@@ -135,6 +135,18 @@ uint64_t orc_render_streaming(const OScene* scene, const OCamera* cam, uint32_t 
                               float* fb_color, float* fb_normal, float* fb_depth,
                               uint32_t* live_counts, int nthreads);
 
+/* One ROW BAND [row0,row1) of one iteration of the streaming mode, for the multi-GPU partition (no
+ * reference equivalent; the reference is single-GPU).  The reference seeds the material RNG from the GLOBAL
+ * compacted slot index; a band reproduces the full-frame result iff, at every bounce, it offsets its local
+ * slot indices by the number of live paths in all lower bands.  exchange(user, bounce, my_live) must return
+ * that number (bounce 0: row0*w).  exchange == NULL: base = 0 from bounce 1 on ("band-local" numbering).
+ * fb_* hold the band's rows only.  Returns the band's ray count. */
+typedef uint32_t (*orc_exchange_fn)(void* user, uint32_t bounce, uint32_t my_live);
+uint64_t orc_render_streaming_band(const OScene* scene, const OCamera* cam, uint32_t w, uint32_t h, uint32_t row0,
+                                   uint32_t row1, uint32_t iteration, uint32_t max_bounces, float* fb_color,
+                                   float* fb_normal, float* fb_depth, uint32_t* live_counts,
+                                   orc_exchange_fn exchange, void* user, int nthreads);
+
 /* Megakernel mode (path_tracer.cu:227-269). */
 uint64_t orc_render_megakernel(const OScene* scene, const OCamera* cam, uint32_t w, uint32_t h,
                                uint32_t iter_begin, uint32_t iter_count, uint32_t max_bounces,

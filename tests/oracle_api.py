@@ -39,6 +39,8 @@ class OIntersection(C.Structure):
 
 assert C.sizeof(ORay) == 32 and C.sizeof(OIntersection) == 48
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32)
+
 BVH_NODE_DTYPE = np.dtype([("aabb_min", "<f4", (3,)), ("aabb_max", "<f4", (3,)),
                            ("first_child_or_primitive", "<u4"), ("primitive_count", "<u4")])
 INTERSECTION_DTYPE = np.dtype({"names": ["t", "point", "normal", "material_id", "side"],
@@ -101,6 +103,10 @@ def lib():
         h.orc_render_streaming.restype = C.c_uint64
         h.orc_render_streaming.argtypes = [C.POINTER(OScene), C.POINTER(OCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        h.orc_render_streaming_band.restype = C.c_uint64
+        h.orc_render_streaming_band.argtypes = [C.POINTER(OScene), C.POINTER(OCamera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, EXCHANGE_FN, C.c_void_p, C.c_int]
         h.orc_render_megakernel.restype = C.c_uint64
         h.orc_render_megakernel.argtypes = [C.POINTER(OScene), C.POINTER(OCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -178,6 +184,25 @@ def render_streaming(flat, camera, w, h, iter_begin, iter_count, max_bounces, nt
     live = np.zeros((iter_count, max_bounces), dtype=np.uint32)
     rays = lib().orc_render_streaming(C.byref(sh.c), C.byref(cam), w, h, iter_begin, iter_count, max_bounces,
                                       color.ctypes.data, normal.ctypes.data, depth.ctypes.data, live.ctypes.data, nthreads)
+    return {"color": color, "normal": normal, "depth": depth, "live": live, "rays": int(rays)}
+
+
+def render_band(flat, camera, w, h, rows, iteration, max_bounces, exchange=None, prev=None, nthreads=0, scene_handle=None):
+    """One iteration of the row band rows=(row0,row1).  exchange(bounce, my_live) -> slot base, or None."""
+    sh = scene_handle or SceneHandle(flat)
+    cam = camera_c(camera)
+    row0, row1 = rows
+    if prev is None:
+        color = np.zeros((row1 - row0, w, 3), dtype=np.float32)
+        normal = np.zeros((row1 - row0, w, 3), dtype=np.float32)
+        depth = np.zeros((row1 - row0, w), dtype=np.float32)
+    else:
+        color, normal, depth = (np.array(prev[k], dtype=np.float32, copy=True) for k in ("color", "normal", "depth"))
+    live = np.zeros(max_bounces, dtype=np.uint32)
+    cb = EXCHANGE_FN((lambda user, bounce, mine: int(exchange(int(bounce), int(mine)))) if exchange else 0)
+    rays = lib().orc_render_streaming_band(C.byref(sh.c), C.byref(cam), w, h, row0, row1, iteration, max_bounces,
+                                           color.ctypes.data, normal.ctypes.data, depth.ctypes.data, live.ctypes.data,
+                                           cb, None, nthreads)
     return {"color": color, "normal": normal, "depth": depth, "live": live, "rays": int(rays)}
 
 

@@ -155,3 +155,57 @@ def test_benchmark_size_rays_against_oracle(pkg, orc, big):
             assert np.array_equal(t >= 0, m)
             assert np.array_equal(t[m], recs["t"][m]) and np.array_equal(nrm[m], recs["normal"][m])
             assert np.array_equal(mat[m], recs["material_id"][m].astype(np.uint32)) and np.array_equal(side[m], recs["side"][m])
+
+
+def test_row_bands_with_global_slot_numbering_equal_full_frame(pkg, small_scenes):
+    """Two contexts = two row bands on one GPU, live counts exchanged per bounce (through the host here, over
+    RCCL in BandRenderer): the assembled image is the single-context image bit for bit; with band-local
+    numbering (what bench.py runs) only band 0 is."""
+    import torch
+    scene, w, h = small_scenes["instances"]
+    flat = scene.build_scene()
+    iters, mb = 2, 6
+    full = frames(pkg, scene, flat, w, h, iters, mb, fif=1)
+    rows = pkg.bands.split_rows(h, 2)
+    pts = []
+    for r in rows:
+        pt = pkg.PathTracer(max_bounces=mb)
+        pt.set_param("frames_in_flight", 1)
+        pt.create_buffers((w, h), flat)
+        pt.set_rows(*r)
+        pt.max_iterations = iters
+        pts.append(pt)
+    base = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for it in range(iters):
+        for pt in pts:
+            pt.trace_begin(scene.camera)
+        for b in range(mb):
+            counts = [pt.read_live_count(b) for pt in pts]
+            base[0] = 0 if b else rows[0][0] * w
+            base[1] = pkg.bands.slot_base_from_counts(counts, 1) if b else rows[1][0] * w
+            torch.cuda.synchronize()
+            for k, pt in enumerate(pts):
+                pt.trace_bounce(b, base.data_ptr() + 4 * k)
+        for pt in pts:
+            pt.trace_end()
+    got = {k: pkg.bands.assemble([pt.download(k) for pt in pts]) for k in ("color", "normal", "depth")}
+    rays = sum(pt.stats()["rays_total"] for pt in pts)
+    for pt in pts:
+        pt.close()
+    for k in ("color", "normal", "depth"):
+        assert np.array_equal(got[k], full[k]), k
+    assert rays == full["stats"]["rays_total"]
+    # band-local numbering
+    local = []
+    for r in rows:
+        with pkg.PathTracer(max_bounces=mb) as pt:
+            pt.create_buffers((w, h), flat)
+            pt.set_rows(*r)
+            pt.max_iterations = iters
+            for _ in range(iters):
+                pt.path_trace(scene.camera)
+            local.append(pt.download("color"))
+    h0 = rows[0][1]
+    assert np.array_equal(local[0], full["color"][:h0])
+    assert not np.array_equal(local[1], full["color"][h0:])
+    assert abs(float(local[1].mean()) - float(full["color"][h0:].mean())) < 0.02
