@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not time the trace kernel with HIP events (diagnostic)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="resolution of the CPU-oracle sample frame")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (the GPU box's CPU share for one GPU is 16)")
     return ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     present()
     fence()
     pt.reset_profile()
-    pt.set_profiling(time_trace_kernel=True, count_tests=False)
+    pt.set_profiling(time_trace_kernel=not args.no_events, count_tests=False)
     rays0 = pt.stats()["rays_total"]
     first_iter = pt.iteration()
 

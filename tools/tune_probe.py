@@ -5,7 +5,7 @@ pkg=g.load_package()
 W,H=1920,1080
 sc=pkg.scenes.heightfield_scene((W,H)); flat=sc.build_scene()
 mesh=list(sc.mesh_map_.values())[0]; flat.bvh,depth=pkg.bvh_from_mesh(mesh)
-for F,waves,refill in ((8,4096,20),(8,8192,20),(8,6144,20),(1,4096,20),(1,8192,20),(4,8192,20),(16,4096,20)):
+for F,waves,refill in ((8,6144,20),(8,6144,20)):
   with pkg.PathTracer(max_bounces=8) as pt:
     pt.set_param('frames_in_flight', F); pt.set_param('traverse_waves', waves); pt.set_param('refill_lanes', refill)
     pt.create_buffers((W,H), flat); pt.max_iterations=1<<30
