@@ -925,74 +925,82 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
 }
 
 // ------------------------------------------------------------------------------------------------
-// variant 3: persistent traversal over the four-wide collapse, exactness restored per candidate
+// variant 3: variant 4's scheme over the four-wide collapse (128-byte nodes: half the dependent loads per ray)
 // ------------------------------------------------------------------------------------------------
-// Because a node that passes the reference's box test implies that all its ancestors pass (boxes nest
-// exactly; IEEE - and / are monotonic), the reference's result for one mesh is: the closest accepted
-// triangle among those whose PARENT box passes the exact test (ties: later in depth-first order).  So the
-// traversal itself only has to be conservative -- never skip a subtree that could hold such a triangle -- and
-// is free to use another node layout: here the reference tree collapsed to four children per 128-byte node
-// (half the dependent loads per ray).  A candidate that survives the triangle test is then checked against
-// its parent's box with the reference's own arithmetic before it is accepted.
-// Rays with a zero / subnormal direction component (0/0 = NaN in the reference's slab test breaks the
-// nesting argument) take the reference-order traversal instead.
-constexpr int kLdsStack = 16;    // (ref, effective near distance) pairs per lane in LDS: 8 KiB per wavefront
+// Conservative FMA slabs on four children per step, children visited nearest first, optimistic acceptance,
+// one exact test of the winner's parent box (see variant 4 below for the argument), results in batches.
+constexpr int kLds4 = 24;  // traversal stack entries per lane in LDS (6 KiB per wavefront); deeper: DScene::spill
 
 template <bool kCount, bool kFirst>
 __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
-                                                     int work_slot, DeviceCounters* counters)
+                                                     int work_slot, DeviceCounters* counters, uint32_t* slow_list)
 {
-  __shared__ uint2 s_stack[kLdsStack * kWave];
+  __shared__ uint32_t s_stack[kLds4 * kWave];
+  uint32_t* stack = s_stack + threadIdx.x;
+  const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
   const uint32_t n = counters->live[bounce];
   if (n == 0u) return;
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
-  const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
-
   if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
   RayFeed feed;
   feed.init(n, &counters->work[work_slot][0][0]);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;
+  bool pending = false;
   uint32_t slot = 0u, cur = 0u, flags = 0u;
   int sp = 0, best_k = -1;
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
+  bool neg_x = false, neg_y = false, neg_z = false;
   float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
   Tally tally;
   uint32_t ray_boxes = 0u;
-  unsigned long long ray_start = 0ull;
-  const unsigned long long wave_start = kCount ? __builtin_readcyclecounter() : 0ull;
 
-  auto push = [&](uint32_t ref, float eff_near) {
-    const uint2 e = make_uint2(ref, __float_as_uint(eff_near));
-    if (sp < kLdsStack) s_stack[sp * kWave + threadIdx.x] = e;
-    else if (sp < kLdsStack + (int)sc.spill_cap) sc.spill[(size_t)(sp - kLdsStack) * sc.spill_stride + gid] = e;
+  auto push = [&](uint32_t ref) {
+    if (sp < kLds4) stack[sp * kWave] = ref;
+    else if (sp < kLds4 + (int)sc.spill_cap) sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x = ref;
     else {
       flags |= kFlagStackOverflow;
       return;
     }
     ++sp;
   };
-  // next entry whose box is not already beyond the closest hit; false when the stack is empty
-  auto pop = [&]() -> bool {
-    while (sp > 0) {
-      --sp;
-      const uint2 e = sp < kLdsStack ? s_stack[sp * kWave + threadIdx.x]
-                                     : sc.spill[(size_t)(sp - kLdsStack) * sc.spill_stride + gid];
-      if (__uint_as_float(e.y) > limit * 1.001f) continue;
-      cur = e.x;
-      return true;
+  auto finalize = [&]() {
+    if (best_k >= 0) {
+      const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
+      const f3 od = normalize(xform_vector(obj->inv_m, rd));
+      float en, ef;
+      if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef), 0)) {
+        slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+        best_k = -2;
+      }
     }
-    return false;
+    if (best_k >= 0) {
+      const float4 tc = tris[3u * (size_t)best_k + 2u];
+      const f3 outward = mk3(tc.y, tc.z, tc.w);
+      const f3 p = ro + rd * best_t;
+      const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
+      const f3 nn = side == 0u ? outward : -outward;
+      hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
+      hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+    } else if (kFirst && best_k == -1) {
+      hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+    }
+    if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
   };
 
   for (;;) {
     const uint64_t idle_mask = __ballot(!active);
     const uint32_t idle = (uint32_t)__popcll(idle_mask);
     const bool more = priv_next < priv_end || !feed.exhausted();
-    if (more && (idle == (uint32_t)kWave || idle >= kRefillLanes)) {
+    if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
+      if (pending) {
+        finalize();
+        pending = false;
+      }
       if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
       const uint32_t mine = priv_next + rank_below(idle_mask);
       const uint32_t range_end = priv_end;
@@ -1017,34 +1025,29 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
           const f3 od = v * (1.0f / scale);
           oo = xform_point(obj->inv_m, ro);
           inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)), 0)) {
-            // degenerate direction: the reference-order traversal, in place (rare)
-            Ray ray;
-            ray.o = ro;
-            ray.d = rd;
-            ray.tmin = tmin;
-            ray.tmax = t_in;
-            Hit rec;
-            rec.t = 0.0f;
-            rec.p = rec.n = mk3(0.f, 0.f, 0.f);
-            rec.mat = 0u;
-            rec.side = 0u;
-            Tally unused;
-            if (ray_mesh<false>(ray, sc, obj, rec, reinterpret_cast<uint32_t*>(s_stack) + threadIdx.x, flags, unused,
-                                2 * kLdsStack)) {
-              hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
-              hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(mat | (rec.side << 31)));
-              wrote = true;
-            }
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow, 0)) {
+            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+            wrote = true;
             go = false;
           } else {
+            const f3 oi = mk3(-(oo.x * inv.x), -(oo.y * inv.y), -(oo.z * inv.z));
+            const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
+            const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
+            const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
+            const f3 tol = mk3(1e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
+                               1e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
+                               1e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
+            oin = oi - tol;
+            oif = oi + tol;
+            neg_x = inv.x < 0.0f;
+            neg_y = inv.y < 0.0f;
+            neg_z = inv.z < 0.0f;
             best_t = t_in;
             best_k = -1;
             limit = scale * best_t;
             cur = sc.bvh4_root;
             sp = 0;
             ray_boxes = 0u;
-            if (kCount) ray_start = __builtin_readcyclecounter();
           }
         }
         if (go) active = true;
@@ -1052,115 +1055,101 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
       }
     }
     if (__ballot(active) == 0ull) {
-      if (priv_next >= priv_end && feed.exhausted()) break;
+      if (priv_next >= priv_end && feed.exhausted()) {
+        if (pending) {
+          finalize();
+          pending = false;
+        }
+        break;
+      }
       continue;
     }
 
     bool done = false;
-    uint32_t leaf_refs[4] = {kNoChild, kNoChild, kNoChild, kNoChild};
-    uint32_t leaf_mask = 0u;
-    if (active) {
-      if (cur & kLeafBit) {  // only a single-triangle mesh starts at a leaf
-        leaf_refs[0] = cur;
-        leaf_mask = 1u;
-        cur = kNoChild;
-      } else {
-        const float4* q = sc.bvh4 + 8u * (size_t)cur;
-        const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5], rf = q[6];
-        float key[4];
-        uint32_t ref[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
-        const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w};
-        const float lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
-        const float hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, hi_z[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+    if (active && !(cur & kLeafBit)) {
+      const float4* q = sc.bvh4 + 8u * (size_t)cur;
+      const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5], rf = q[6];
+      // near / far plane of each axis by the sign of 1/d; one FMA per plane
+      const float4 nx = neg_x ? mxx : mnx, fx = neg_x ? mnx : mxx;
+      const float4 ny = neg_y ? mxy : mny, fy = neg_y ? mny : mxy;
+      const float4 nz = neg_z ? mxz : mnz, fz = neg_z ? mnz : mxz;
+      float key[4];
+      uint32_t ref[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
+      const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, nya[4] = {ny.x, ny.y, ny.z, ny.w}, nza[4] = {nz.x, nz.y, nz.z, nz.w};
+      const float fxa[4] = {fx.x, fx.y, fx.z, fx.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float ax = (lo_x[c] - oo.x) * inv.x, bx = (hi_x[c] - oo.x) * inv.x;
-          const float ay = (lo_y[c] - oo.y) * inv.y, by = (hi_y[c] - oo.y) * inv.y;
-          const float az = (lo_z[c] - oo.z) * inv.z, bz = (hi_z[c] - oo.z) * inv.z;
-          const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-          const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-          const bool valid = ref[c] != kNoChild;
-          const bool leaf = (ref[c] & kLeafBit) != 0u;
-          // skip only what is missed by far more than rounding (conservative), or lies beyond the closest
-          // hit / behind the origin with a margin
-          const float tol = (leaf ? 1e-4f : 1e-5f) * (fabsf(tn) + fabsf(tf)) + 1e-30f;
-          const bool go = valid && !((tf - tn) < -tol) && !box_culled(tn, tf, limit);
-          if (kCount && valid) { ++tally.boxes; ++ray_boxes; }
-          if (go && leaf) {
-            leaf_refs[c] = ref[c];
-            leaf_mask |= 1u << c;
-          }
-          key[c] = (go && !leaf) ? tn - 1e-3f * (tf - tn) : __builtin_inff();
-        }
-        // sort the (up to four) inner children by entry distance: 5 compare-exchanges
-        auto cx = [&](int a, int b) {
-          if (key[b] < key[a]) {
-            const float tk = key[a];
-            key[a] = key[b];
-            key[b] = tk;
-            const uint32_t tr = ref[a];
-            ref[a] = ref[b];
-            ref[b] = tr;
-          }
-        };
-        cx(0, 1);
-        cx(2, 3);
-        cx(0, 2);
-        cx(1, 3);
-        cx(1, 2);
-        if (key[3] < __builtin_inff()) push(ref[3], key[3]);
-        if (key[2] < __builtin_inff()) push(ref[2], key[2]);
-        if (key[1] < __builtin_inff()) push(ref[1], key[1]);
-        cur = key[0] < __builtin_inff() ? ref[0] : kNoChild;
+      for (int c = 0; c < 4; ++c) {
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(nxa[c], inv.x, oin.x), __builtin_fmaf(nya[c], inv.y, oin.y)),
+                               __builtin_fmaf(nza[c], inv.z, oin.z));
+        const float tf = fminf(fminf(__builtin_fmaf(fxa[c], inv.x, oif.x), __builtin_fmaf(fya[c], inv.y, oif.y)),
+                               __builtin_fmaf(fza[c], inv.z, oif.z));
+        const bool valid = ref[c] != kNoChild;
+        const bool go = valid && !((tf - tn) < -1e-4f * (fabsf(tn) + fabsf(tf))) && !box_culled(tn, tf, limit);
+        if (kCount && valid) { ++tally.boxes; ++ray_boxes; }
+        key[c] = go ? tn : __builtin_inff();
       }
-      // triangles of the leaf children that survived (ray_triangle_intersection_test, intersections.cuh:49-85)
-      while (leaf_mask) {
-        const int c = __builtin_ctz(leaf_mask);
-        leaf_mask &= leaf_mask - 1u;
-        const uint32_t k = (c == 0 ? leaf_refs[0] : c == 1 ? leaf_refs[1] : c == 2 ? leaf_refs[2] : leaf_refs[3]) & ~kLeafBit;
-        const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
-        if (kCount) ++tally.tris;
-        const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
-        const f3 h = cross(rd, e2);
-        const float a = dot(e1, h);
-        if (a > -0.0000001f && a < 0.0000001f) continue;
+      // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
+      auto cx = [&](int a, int b) {
+        const bool sw = key[b] < key[a];
+        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
+        const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];
+        key[a] = ka;
+        key[b] = kb;
+        ref[a] = ra;
+        ref[b] = rb;
+      };
+      cx(0, 1);
+      cx(2, 3);
+      cx(0, 2);
+      cx(1, 3);
+      cx(1, 2);
+      if (key[3] < __builtin_inff()) push(ref[3]);
+      if (key[2] < __builtin_inff()) push(ref[2]);
+      if (key[1] < __builtin_inff()) push(ref[1]);
+      if (key[0] < __builtin_inff()) {
+        cur = ref[0];
+      } else if (sp == 0) {
+        done = true;
+      } else {
+        --sp;
+        cur = sp < kLds4 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x;
+      }
+    }
+    if (active && !done && (cur & kLeafBit)) {
+      // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
+      const uint32_t k = cur & ~kLeafBit;
+      const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
+      if (kCount) ++tally.tris;
+      const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
+      const f3 h = cross(rd, e2);
+      const float a = dot(e1, h);
+      if (!(a > -0.0000001f && a < 0.0000001f)) {
         const float f = 1.0f / a;
         const f3 sv = ro - p0;
         const float u = f * dot(sv, h);
-        if (u < 0.0f || u > 1.0f) continue;
-        const f3 qv = cross(sv, e1);
-        const float w = f * dot(rd, qv);
-        if (w < 0.0f || u + w > 1.0f) continue;
-        const float t = f * dot(e2, qv);
-        if (t < tmin || !(t < best_t || (t == best_t && (int)k > best_k))) continue;
-        // reachable in the reference?  <=> the parent's box passes the reference's own test
-        const float4 pb0 = sc.leaf_parent[2u * (size_t)k], pb1 = sc.leaf_parent[2u * (size_t)k + 1u];
-        const f3 od = normalize(xform_vector(obj->inv_m, rd));
-        float en, ef;
-        if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef)) continue;
-        best_t = t;
-        best_k = (int)k;
-        limit = scale * t;
+        if (!(u < 0.0f || u > 1.0f)) {
+          const f3 qv = cross(sv, e1);
+          const float w = f * dot(rd, qv);
+          if (!(w < 0.0f || u + w > 1.0f)) {
+            const float t = f * dot(e2, qv);
+            if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
+              best_t = t;
+              best_k = (int)k;
+              limit = scale * t;
+            }
+          }
+        }
       }
-      if (cur == kNoChild && !pop()) done = true;
+      if (sp == 0) {
+        done = true;
+      } else {
+        --sp;
+        cur = sp < kLds4 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x;
+      }
     }
     if (done) {
-      if (best_k >= 0) {
-        const float4 tc = tris[3u * (size_t)best_k + 2u];
-        const f3 outward = mk3(tc.y, tc.z, tc.w);
-        const f3 p = ro + rd * best_t;
-        const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
-        const f3 nn = side == 0u ? outward : -outward;
-        hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
-        hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
-      } else if (kFirst) {
-        hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-      }
-      if (kCount) {
-        atomicMax(&counters->max_box_tests[bounce], ray_boxes);
-        atomicMax(&counters->max_ray_cycles[bounce], (uint32_t)(__builtin_readcyclecounter() - ray_start));
-      }
       active = false;
+      pending = true;
     }
   }
   if (flags) atomicOr(&counters->flags, flags);
@@ -1174,7 +1163,6 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
     if (threadIdx.x == 0u) {
       atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
       atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
-      atomicMax(&counters->max_wave_cycles[bounce], (uint32_t)(__builtin_readcyclecounter() - wave_start));
     }
   }
 }
@@ -1899,11 +1887,11 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
   }
   if (variant == 3) {
     if (count_tests) {
-      if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
-      else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+      if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+      else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
     } else {
-      if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
-      else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+      if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+      else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
     }
     return;
   }

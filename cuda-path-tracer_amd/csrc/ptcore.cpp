@@ -91,7 +91,7 @@ struct ptc_ctx {
   bool have_cam = false;
   uint64_t frames = 0;
 
-  int trace_variant = 4;  // 4: persistent lanes, conservative FMA slabs, exact check of the winner (default); 2, 3: earlier forms; 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
+  int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse, conservative FMA slabs, exact check of the winner (default); 4: same over two-wide records; 2: exact tests in the loop 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
   struct Segment {
     bool mesh;
     uint32_t begin, end;  // object range (mesh: one object)
@@ -445,9 +445,12 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   // whatever exceeds the LDS part (16 entries) goes to this per-thread overflow area
   d.spill_cap = 0;
   if (node_count) {
-    const uint32_t need = std::max(depth + 2u, 3u * w4.depth + 2u);
-    if (need > 16u) {
-      d.spill_cap = need - 16u;
+    // beyond the LDS part: 16 entries (two-wide kernel) / 24 (four-wide kernel)
+    const uint32_t need2 = depth + 2u > 16u ? depth + 2u - 16u : 0u;
+    const uint32_t need4 = 3u * w4.depth + 2u > 24u ? 3u * w4.depth + 2u - 24u : 0u;
+    const uint32_t need = std::max(need2, need4);
+    if (need > 0u) {
+      d.spill_cap = need;
       if (int rc = dev_alloc(ctx, ctx->scene_allocs, &d.spill, (size_t)d.spill_cap * d.spill_stride)) return rc;
     }
   }
@@ -707,7 +710,7 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         launch_traverse(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
                         ctx->count_tests, ctx->traverse_waves, ctx->trace_variant, sl.slow_list);
         if (int rc = timed_end(tl)) return rc;
-        if (ctx->trace_variant == 4) launch_slow_rays(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters);
+        if (ctx->trace_variant >= 3) launch_slow_rays(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters);
       } else {
         launch_spheres(sl.stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
                        sl.chunk_counts, sl.counters);

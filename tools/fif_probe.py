@@ -6,7 +6,7 @@ W,H=1920,1080
 sc=pkg.scenes.heightfield_scene((W,H)); flat=sc.build_scene()
 mesh=list(sc.mesh_map_.values())[0]; flat.bvh,depth=pkg.bvh_from_mesh(mesh)
 ref=None
-for variant,F in ((2,8),(4,8),(4,4),(4,1),(2,1)):
+for variant,F in ((4,8),(3,8),(4,1),(3,1)):
   with pkg.PathTracer(max_bounces=8) as pt:
     pt.set_param('frames_in_flight', F)
     pt.create_buffers((W,H), flat); pt.max_iterations=1<<30; pt.set_trace_variant(variant)
