@@ -167,8 +167,9 @@ void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, u
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);
 void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst);
-void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_begin, uint32_t pix_count, const float4* color,
-                         const float4* nd, float4* out, int step_width, DDenoise params);
+void launch_denoise_positions(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* nd, float4* pos);
+void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* color, const float4* nd,
+                         const float4* pos, float4* out, int step_width, DDenoise params);
 void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
                       DHits hits, DeviceCounters* counters, int variant);
 void launch_selftest(hipStream_t s, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,

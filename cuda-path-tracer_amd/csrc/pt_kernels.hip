@@ -1755,23 +1755,38 @@ __global__ __launch_bounds__(256) void k_pack(const float4* buf, uint32_t pix_co
   }
 }
 
-// denoising_kernel, denoising/edge_avoiding_a_trous_denoiser.cu:24-86.
-// The reference clamps taps to [0,W] x [0,H] INCLUSIVE (cu:39-42), so column W aliases the next row's
-// column 0 and row H is out of bounds; an index beyond the array reads element W*H-1 here.
-__global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count, const float4* color, const float4* nd,
-                                                 float4* out, int step_width, DDenoise prm)
+// denoising_kernel, denoising/edge_avoiding_a_trous_denoiser.cu:24-86, in two kernels.
+// The reference rebuilds the view ray of every one of the 25 taps in every pass (generate_ray: a normalise and
+// a matrix product each); the tap positions depend only on (pixel, accumulated depth), so k_denoise_positions
+// computes them once per denoise call and the four passes read them back (16 B per tap instead of ~40
+// instructions).  The reference clamps taps to [0,W] x [0,H] INCLUSIVE (cu:39-42): column W aliases the next
+// row's column 0 but keeps its own view ray, and row H is out of bounds; taps on column W / row H therefore
+// rebuild their ray here (edge pixels only), and an index beyond the array reads element W*H-1.
+__global__ __launch_bounds__(256) void k_denoise_positions(DCamera cam, uint32_t pix_count, const float4* nd, float4* pos)
 {
   const uint32_t index = blockIdx.x * 256u + threadIdx.x;
   if (index >= pix_count) return;
-  const uint32_t W = cam.width, H = cam.height;
-  const int x = (int)(index % W), y = (int)(index / W);
-  const float kernel[3] = {3.f / 8.f, 1.f / 4.f, 1.f / 16.f};
-  const f3 cval = xyz(color[index]);
-  const float4 ndc = nd[index];
-  const f3 nval = xyz(ndc);
+  const int x = (int)(index % cam.width), y = (int)(index / cam.width);
   f3 ro, rd;
   generate_ray(cam, (float)x + 0.5f, (float)y + 0.5f, ro, rd);
-  const f3 pval = ro + rd * ndc.w;
+  const f3 p = ro + rd * nd[index].w;
+  pos[index] = make_float4(p.x, p.y, p.z, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count, const float4* color, const float4* nd,
+                                                 const float4* pos, float4* out, int step_width, DDenoise prm)
+{
+  // 16x16 pixel tiles: neighbouring threads share most of their (dilated) taps in L1/L2
+  const uint32_t W = cam.width, H = cam.height;
+  const uint32_t tiles_x = (W + 15u) / 16u;
+  const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x = (int)(tx * 16u + (threadIdx.x & 15u)), y = (int)(ty * 16u + (threadIdx.x >> 4));
+  if (x >= (int)W || y >= (int)H) return;
+  const uint32_t index = (uint32_t)x + (uint32_t)y * W;
+  const float kernel[3] = {3.f / 8.f, 1.f / 4.f, 1.f / 16.f};
+  const f3 cval = xyz(color[index]);
+  const f3 nval = xyz(nd[index]);
+  const f3 pval = xyz(pos[index]);
   f3 sum = mk3(0.f, 0.f, 0.f);
   float cum_w = 0.0f;
   const float step2 = (float)(step_width * step_width);
@@ -1791,9 +1806,14 @@ __global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count
       t = nval - xyz(ndt);
       dist2 = sel_max(dot(t, t) / step2, 0.0f);
       const float n_w = sel_min(expf(-dist2 / prm.n_phi), 1.0f);
-      f3 to, td;
-      generate_ray(cam, (float)u + 0.5f, (float)v + 0.5f, to, td);
-      const f3 ptmp = to + td * ndt.w;
+      f3 ptmp;
+      if (u == (int)W || v == (int)H) {  // the reference's off-by-one taps keep their own view ray
+        f3 to, td;
+        generate_ray(cam, (float)u + 0.5f, (float)v + 0.5f, to, td);
+        ptmp = to + td * ndt.w;
+      } else {
+        ptmp = xyz(pos[ti]);
+      }
       t = pval - ptmp;
       dist2 = dot(t, t);
       const float p_w = sel_min(expf(-dist2 / prm.p_phi), 1.0f);
@@ -1934,12 +1954,15 @@ void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which
 {
   hipLaunchKernelGGL(k_pack, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, buf, pix_count, which, dst);
 }
-void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_begin, uint32_t pix_count, const float4* color,
-                         const float4* nd, float4* out, int step_width, DDenoise params)
+void launch_denoise_positions(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* nd, float4* pos)
 {
-  (void)pix_begin;
-  hipLaunchKernelGGL(k_denoise, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, pix_count, color, nd, out,
-                     step_width, params);
+  hipLaunchKernelGGL(k_denoise_positions, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, pix_count, nd, pos);
+}
+void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* color, const float4* nd,
+                         const float4* pos, float4* out, int step_width, DDenoise params)
+{
+  const uint32_t tiles = div_up(cam.width, 16u) * div_up(cam.height, 16u);
+  hipLaunchKernelGGL(k_denoise, dim3(tiles), dim3(256), 0, s, cam, pix_count, color, nd, pos, out, step_width, params);
 }
 void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
                       DHits hits, DeviceCounters* counters, int variant)

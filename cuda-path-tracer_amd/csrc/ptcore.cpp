@@ -77,6 +77,7 @@ struct ptc_ctx {
   DFrame fb{};
   float4* den_a = nullptr;
   float4* den_b = nullptr;
+  float4* den_pos = nullptr;     // per-pixel view-space hit position of the accumulated depth (denoiser)
   const float4* result = nullptr;
   float* pack_buf = nullptr;     // 3 floats / pixel staging for downloads
   uint32_t* rgba_buf = nullptr;  // staging for host presents
@@ -529,6 +530,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   }
   if (int rc = dev_alloc(ctx, pool, &ctx->den_a, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->den_b, P)) return rc;
+  if (int rc = dev_alloc(ctx, pool, &ctx->den_pos, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->pack_buf, P * 3u)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->rgba_buf, P)) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->fb.color4, 0, P * sizeof(float4), ctx->stream));
@@ -655,9 +657,11 @@ int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
   ctx->have_cam = true;
   const int f = ctx->iteration % (int)ctx->slots.size();
   auto& sl = ctx->slots[(size_t)f];
-  // the slot's previous frame has been enqueued on the same stream, so its buffers are free in stream order;
-  // a main-stream consumer that still reads the framebuffers (denoise) must finish before anything is folded in
-  if (ctx->main_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
+  // the slot's previous frame has been enqueued on the same stream, so its buffers are free in stream order.
+  // A main-stream consumer that still reads the framebuffers (denoise) must finish before anything is folded
+  // in: with staging that is only the accumulate at the end of the frame (so tracing overlaps the denoise of
+  // the previous frame); without staging the shade kernels write the framebuffers directly.
+  if (ctx->main_valid && !ctx->staging()) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
   sl.cur = 0;
   sl.work_slot = 0;
   sl.bounces_done = 0;
@@ -740,6 +744,7 @@ int ptc_trace_end(ptc_ctx* ctx)
   if (ctx->staging()) {
     // fold this sample in after the previous iteration's fold (running means do not commute)
     if (ctx->order_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->order_event, 0));
+    if (ctx->main_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
     launch_accumulate(sl.stream, (uint32_t)ctx->iteration, sl.stage, ctx->fb, ctx->pix_count);
     if (int rc = check_last(ctx, "accumulate")) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->order_event, sl.stream));
@@ -835,8 +840,9 @@ int ptc_denoise(ptc_ctx* ctx)
   const float4* color = ctx->fb.color4;
   float4* back = ctx->den_a;
   float4* front = ctx->den_b;
+  if (ctx->den.filter_size >= 1) launch_denoise_positions(ctx->stream, ctx->cam, ctx->pix_count, ctx->fb.nd4, ctx->den_pos);
   for (int step = 1; step <= ctx->den.filter_size; step *= 2) {
-    launch_denoise_pass(ctx->stream, ctx->cam, ctx->pix_begin, ctx->pix_count, color, ctx->fb.nd4, back, step, prm);
+    launch_denoise_pass(ctx->stream, ctx->cam, ctx->pix_count, color, ctx->fb.nd4, ctx->den_pos, back, step, prm);
     const float4* new_color = back;
     float4* new_back = front;
     float4* new_front = back;
