@@ -4,7 +4,7 @@ The directory name contains a hyphen, so it is imported through ``__graft_entry_
 under the module name ``cuda_path_tracer_amd``.  All rendering happens in ``libptcore.so``
 (``csrc/``, C ABI in ``include/ptcore.h``); the Python files are the host-side mirror of the reference's
 ``PathTracer`` / ``SceneDescription`` interface used by the tests and by bench.py."""
-from . import _capi, bands, glmlite, scenes
+from . import _capi, bands, glmlite, json_parser, scenes
 from ._capi import LIB_PATH, PtcError, lib
 from .path_tracer import DisplayBufferType, EdgeAvoidingATrousDenoiser, GPUMethod, PathTracer
 from .scene_description import (Camera, DielectricMaterial, DiffuseMateral, FlatScene, Mesh, MetalMaterial,
@@ -12,4 +12,4 @@ from .scene_description import (Camera, DielectricMaterial, DiffuseMateral, Flat
 
 __all__ = ["PathTracer", "GPUMethod", "DisplayBufferType", "EdgeAvoidingATrousDenoiser", "SceneDescription", "Camera",
            "Sphere", "Mesh", "DiffuseMateral", "MetalMaterial", "DielectricMaterial", "FlatScene", "bvh_from_mesh",
-           "scenes", "bands", "glmlite", "lib", "LIB_PATH", "PtcError"]
+           "scenes", "bands", "glmlite", "json_parser", "lib", "LIB_PATH", "PtcError"]
