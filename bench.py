@@ -9,9 +9,10 @@ primary rays included.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the frame is split into N contiguous row bands, one process per GPU; no data-path collective
-during tracing; the bands' radiance is gathered to rank 0 over RCCL once, at present time, inside the
-timed region.  Fixed total work -> "scaling": "strong".
+N > 1: the frame's rows are dealt to the N ranks in blocks of 8 rows (round-robin: sky rows are cheap, terrain
+rows expensive, so contiguous bands would be unbalanced), one process per GPU; no data-path collective during
+tracing; the ranks' radiance is gathered to rank 0 over RCCL once, at present time, inside the timed region,
+and scattered back into frame order there.  Fixed total work -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 with the contract fields plus:
   roofline      dominant kernel = the closest-hit (trace) kernel; achieved = algorithmic bytes of all its
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--no-events", action="store_true", help="do not time the trace kernel with HIP events (diagnostic)")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="resolution of the CPU-oracle sample frame")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (the GPU box's CPU share for one GPU is 16)")
@@ -63,9 +66,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if rehearse else "cuda"
 
     pkg = graft.load_package()
     W, H, MB = args.width, args.height, args.max_bounces
@@ -77,28 +87,40 @@ def main():
     flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)
     bvh_build_s = time.perf_counter() - t0
 
-    # contiguous row bands (cuda-path-tracer_amd/bands.py)
-    bands = pkg.bands.split_rows(H, world)
-    rows = [b[0] for b in bands] + [H]
-    row0, row1 = bands[rank]
+    # rows in blocks of BLOCK_ROWS dealt round-robin over the ranks (cuda-path-tracer_amd/bands.py)
+    BLOCK_ROWS = 8
+    rank_rows = pkg.bands.interleaved_rows(H, world, BLOCK_ROWS)
 
     pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
     pt.create_buffers((W, H), flat)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
-        pt.set_rows(row0, row1)
+        pt.set_interleave(rank, world, BLOCK_ROWS)
     pt.max_iterations = 1 << 30
-    band_pixels = (row1 - row0) * W
-    band_color = torch.empty((band_pixels, 3), dtype=torch.float32, device="cuda")
-    gathered = None
+    # gather needs equal sizes on every rank: pad each rank's rows to the largest share
+    max_rows = max(len(rr) for rr in rank_rows)
+    band_color = torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda")
+    gathered = frame = row_index = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty(((rows[r + 1] - rows[r]) * W, 3), dtype=torch.float32, device="cuda") for r in range(world)]
+        gathered = [torch.empty((max_rows, W, 3), dtype=torch.float32, device="cuda") for r in range(world)]
+        frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        row_index = [torch.tensor(rank_rows[r], dtype=torch.long, device="cuda") for r in range(world)]
 
     def present():
-        """gather of per-band radiance at present time (the only inter-GPU traffic)"""
+        """gather of per-rank radiance at present time (the only inter-GPU traffic) + back into frame order"""
         pt.download_to_device("color", band_color.data_ptr())
         if world > 1:
-            dist.gather(band_color, gathered if rank == 0 else None, dst=0)
+            if rehearse:
+                parts = [torch.empty(g.shape, dtype=g.dtype) for g in gathered] if rank == 0 else None
+                dist.gather(band_color.cpu(), parts, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[r].copy_(parts[r])
+            else:
+                dist.gather(band_color, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    frame.index_copy_(0, row_index[r], gathered[r][: len(rank_rows[r])])
 
     def fence():
         if world > 1:
@@ -128,10 +150,10 @@ def main():
 
     # max over ranks of the elapsed time, sum of rays
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        r = torch.tensor([rays], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays = int(r.item())
 
@@ -200,7 +222,7 @@ def main():
                                    f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
                        "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
                        "resolution": [W, H], "max_bounces": MB, "rays_per_step": round(rays / args.steps),
-                       "live_per_bounce_last_frame_rank0": last_live, "partition": f"{world} row band(s)",
+                       "live_per_bounce_last_frame_rank0": last_live, "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks",
                        "bvh_build_s": round(bvh_build_s, 3)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -93,6 +93,7 @@ SIGNATURES = {
     "ptc_upload_scene": (C.c_int, [_P, C.POINTER(ptc_scene_desc)]),
     "ptc_resize": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "ptc_set_rows": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ptc_set_interleave": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ptc_restart": (C.c_int, [_P]),
     "ptc_iteration": (C.c_int, [_P]),
     "ptc_set_iteration": (C.c_int, [_P, C.c_int]),

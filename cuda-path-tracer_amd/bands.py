@@ -25,6 +25,22 @@ def slot_base_from_counts(counts, rank):
     return int(np.sum(np.asarray(counts[:rank], dtype=np.uint64)))
 
 
+def interleaved_rows(height, world, block_rows):
+    """For each rank the list of global row indices it renders under ptc_set_interleave, in local order."""
+    blocks = (height + block_rows - 1) // block_rows
+    return [[y for gb in range(r, blocks, world) for y in range(gb * block_rows, min(height, (gb + 1) * block_rows))]
+            for r in range(world)]
+
+
+def assemble_interleaved(bands, height, world, block_rows):
+    """Scatter per-rank packed rows back into the full frame."""
+    rows = interleaved_rows(height, world, block_rows)
+    out = np.empty((height,) + tuple(bands[0].shape[1:]), dtype=bands[0].dtype)
+    for r in range(world):
+        out[rows[r]] = bands[r]
+    return out
+
+
 def assemble(bands):
     """Stack per-band arrays (rows first) into the full frame, in rank order."""
     return np.concatenate(list(bands), axis=0)

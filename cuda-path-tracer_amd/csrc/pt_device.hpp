@@ -93,6 +93,27 @@ struct DCamera {
   uint32_t width, height;
 };
 
+// Which pixels of the frame this context renders.  Contiguous (nranks == 1): pixel = pix_begin + s.
+// Interleaved (multi-GPU, load-balanced): the frame is cut into blocks of `block_rows` rows dealt round-robin to
+// `nranks` contexts; local row lr is row ((lr / block_rows) * nranks + rank) * block_rows + lr % block_rows.
+struct DBand {
+  uint32_t pix_begin, width, rank, nranks, block_rows;
+};
+PT_HD uint32_t band_pixel(const DBand& b, uint32_t s)
+{
+  if (b.nranks <= 1u) return b.pix_begin + s;
+  const uint32_t lr = s / b.width, x = s - lr * b.width;
+  const uint32_t y = ((lr / b.block_rows) * b.nranks + b.rank) * b.block_rows + lr % b.block_rows;
+  return y * b.width + x;
+}
+PT_HD uint32_t band_local(const DBand& b, uint32_t pixel)
+{
+  if (b.nranks <= 1u) return pixel - b.pix_begin;
+  const uint32_t y = pixel / b.width, x = pixel - y * b.width;
+  const uint32_t lr = ((y / b.block_rows) / b.nranks) * b.block_rows + y % b.block_rows;
+  return lr * b.width + x;
+}
+
 // Live-path state, one float4 per path and array (48 B/path):
 //   o4 = origin.xyz, bits(pixel | tmin_flag<<31)   tmin_flag: t_min is 1e-5 (after a dielectric) instead of 1e-4
 //   d4 = direction.xyz, unused
@@ -139,7 +160,7 @@ struct DDenoise {
 };
 
 // ---- launch interface (implemented in pt_kernels.hip) ----
-void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
+void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters);
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
@@ -161,9 +182,9 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
                  DeviceCounters* counters);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
                   uint32_t iteration, uint32_t acc_iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
-                  const uint32_t* chunk_offsets, DFrame fb, uint32_t pix_begin, DeviceCounters* counters);
+                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters);
 void launch_accumulate(hipStream_t s, uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count);
-void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, uint32_t pix_begin,
+void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);
 void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst);

@@ -536,8 +536,8 @@ __device__ __forceinline__ void generate_ray(const DCamera& cam, float fx, float
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-// raygen_kernel, ray_gen.cu:11-32.  Slot s of this context holds pixel pix_begin + s.
-__global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
+// raygen_kernel, ray_gen.cu:11-32.  Slot s of this context holds pixel band_pixel(band, s).
+__global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration, DBand band, uint32_t pix_count,
                                                 DPaths paths, DeviceCounters* counters)
 {
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration,
   if (blockIdx.x == 0u)  // fetch cursors of this frame's persistent traversal launches
     for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0][0])[i * 32u] = 0u;
   if (s >= pix_count) return;
-  const uint32_t pixel = pix_begin + s;
+  const uint32_t pixel = band_pixel(band, s);
   const uint32_t x = pixel % cam.width, y = pixel / cam.width;
   Minstd rng;
   rng.seed(path_seed(pixel, iteration));
@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, cons
 __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, uint32_t iteration,
                                                uint32_t acc_iteration, int bounce, int last_bounce,
                                                const uint32_t* slot_base, const uint32_t* chunk_offsets, DFrame fb,
-                                               uint32_t pix_begin, DeviceCounters* counters)
+                                               DBand band, DeviceCounters* counters)
 {
   const uint32_t n = counters->live[bounce];
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
     color = xyz(t4);
     pixbits = __float_as_uint(o4.w);
     const uint32_t pixel = pixbits & 0x7fffffffu;
-    const uint32_t local_pixel = pixel - pix_begin;
+    const uint32_t local_pixel = band_local(band, pixel);
     bool tmin_flag = (pixbits >> 31) != 0u;
 
     if (tp.x < 0.0f) {
@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_accumulate(uint32_t iteration, DFrame s
 
 // path_tracing_mega_kernel, path_tracer.cu:227-269: the whole path in one thread, one RNG stream per
 // pixel (a different image from streaming mode at the same seed -- a property of the reference).
-__global__ __launch_bounds__(kWave) void k_megakernel(DScene sc, DCamera cam, uint32_t iteration, uint32_t pix_begin,
+__global__ __launch_bounds__(kWave) void k_megakernel(DScene sc, DCamera cam, uint32_t iteration, DBand band,
                                                       uint32_t pix_count, int max_bounces, DFrame fb,
                                                       DeviceCounters* counters)
 {
@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(kWave) void k_megakernel(DScene sc, DCamera cam, ui
   const uint32_t s = blockIdx.x * kWave + threadIdx.x;
   uint32_t rays = 0u, flags = 0u;
   if (s < pix_count) {
-    const uint32_t pixel = pix_begin + s;
+    const uint32_t pixel = band_pixel(band, s);
     const uint32_t x = pixel % cam.width, y = pixel / cam.width;
     Minstd rng;
     rng.seed(path_seed(pixel, iteration));
@@ -1846,10 +1846,10 @@ __global__ void k_selftest(const float* a, const float* b, uint32_t n, float* ou
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
-void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, uint32_t pix_begin, uint32_t pix_count,
+void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters)
 {
-  hipLaunchKernelGGL(k_raygen, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, iteration, pix_begin, pix_count,
+  hipLaunchKernelGGL(k_raygen, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, iteration, band, pix_count,
                      paths, counters);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
@@ -1931,19 +1931,19 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
 }
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
                   uint32_t iteration, uint32_t acc_iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
-                  const uint32_t* chunk_offsets, DFrame fb, uint32_t pix_begin, DeviceCounters* counters)
+                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters)
 {
   hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u)), dim3(256), 0, s, scene, in, out, hits, iteration,
-                     acc_iteration, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, pix_begin, counters);
+                     acc_iteration, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, band, counters);
 }
 void launch_accumulate(hipStream_t s, uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count)
 {
   hipLaunchKernelGGL(k_accumulate, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, iteration, stage, fb, pix_count);
 }
-void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, uint32_t pix_begin,
+void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters)
 {
-  hipLaunchKernelGGL(k_megakernel, dim3(div_up(pix_count, kWave)), dim3(kWave), 0, s, scene, cam, iteration, pix_begin,
+  hipLaunchKernelGGL(k_megakernel, dim3(div_up(pix_count, kWave)), dim3(kWave), 0, s, scene, cam, iteration, band,
                      pix_count, max_bounces, fb, counters);
 }
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba)

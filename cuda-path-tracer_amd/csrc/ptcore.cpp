@@ -47,6 +47,7 @@ struct ptc_ctx {
   // frame
   uint32_t width = 0, height = 0;
   uint32_t pix_begin = 0, pix_count = 0, pix_capacity = 0;
+  DBand band{0, 0, 0, 1, 0};
   std::vector<void*> frame_allocs;
   // Frames in flight: consecutive iterations are independent until they are folded into the framebuffer, and
   // the tail of every bounce is a handful of long rays (latency-bound), so iteration i runs on stream i % F
@@ -541,6 +542,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   ctx->width = width;
   ctx->height = height;
   ctx->pix_begin = 0;
+  ctx->band = DBand{0u, width, 0u, 1u, 0u};
   ctx->pix_count = (uint32_t)P;
   ctx->pix_capacity = (uint32_t)P;
   ctx->result = ctx->fb.color4;
@@ -557,6 +559,23 @@ int ptc_set_rows(ptc_ctx* ctx, uint32_t row_begin, uint32_t row_end)
   if (int rc = sync_frames(ctx)) return rc;
   ctx->pix_begin = row_begin * ctx->width;
   ctx->pix_count = (row_end - row_begin) * ctx->width;
+  ctx->band = DBand{ctx->pix_begin, ctx->width, 0u, 1u, 0u};
+  return ptc_restart(ctx);
+}
+
+int ptc_set_interleave(ptc_ctx* ctx, uint32_t rank, uint32_t nranks, uint32_t block_rows)
+{
+  if (!ctx || !ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
+  if (nranks == 0 || rank >= nranks || block_rows == 0) return fail(ctx, PTC_ERR_INVALID, "bad interleave");
+  if (int rc = bind_device(ctx)) return rc;
+  if (int rc = sync_frames(ctx)) return rc;
+  uint32_t rows = 0;
+  const uint32_t blocks = (ctx->height + block_rows - 1u) / block_rows;
+  for (uint32_t gb = rank; gb < blocks; gb += nranks) rows += std::min(block_rows, ctx->height - gb * block_rows);
+  if (rows == 0) return fail(ctx, PTC_ERR_INVALID, "this rank gets no rows");
+  ctx->pix_begin = 0;
+  ctx->pix_count = rows * ctx->width;
+  ctx->band = DBand{0u, ctx->width, rank, nranks, block_rows};
   return ptc_restart(ctx);
 }
 
@@ -665,7 +684,7 @@ int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
   sl.cur = 0;
   sl.work_slot = 0;
   sl.bounces_done = 0;
-  launch_raygen(sl.stream, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count, sl.paths[0], sl.counters);
+  launch_raygen(sl.stream, ctx->cam, (uint32_t)ctx->iteration, ctx->band, ctx->pix_count, sl.paths[0], sl.counters);
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->active_slot = f;
   return PTC_OK;
@@ -730,7 +749,7 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters);
   launch_shade(sl.stream, ctx->scene, in, out, sl.hits, ctx->pix_count, (uint32_t)ctx->iteration,
                ctx->staging() ? 0u : (uint32_t)ctx->iteration, bounce, last, slot_base_dev, sl.chunk_offsets, sl.stage,
-               ctx->pix_begin, sl.counters);
+               ctx->band, sl.counters);
   sl.cur ^= 1;
   sl.bounces_done = bounce + 1;
   return check_last(ctx, "bounce");
@@ -803,7 +822,7 @@ int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
     auto& sl = ctx->slots[0];
     ctx->cam = make_camera(*camera, ctx->width, ctx->height);
     ctx->have_cam = true;
-    launch_megakernel(sl.stream, ctx->scene, ctx->cam, (uint32_t)ctx->iteration, ctx->pix_begin, ctx->pix_count,
+    launch_megakernel(sl.stream, ctx->scene, ctx->cam, (uint32_t)ctx->iteration, ctx->band, ctx->pix_count,
                       ctx->max_bounces, ctx->fb, sl.counters);
     if (int rc = check_last(ctx, "megakernel")) return rc;
     HIP_TRY(ctx, hipEventRecord(sl.done, sl.stream));

@@ -123,6 +123,14 @@ class PathTracer:
         self._check(self._lib.ptc_set_rows(self._ctx, int(row_begin), int(row_end)))
         self._rows = (int(row_begin), int(row_end))
 
+    def set_interleave(self, rank, nranks, block_rows):
+        """Rows dealt in blocks of block_rows round-robin over nranks contexts (load-balanced multi-GPU split)."""
+        self._check(self._lib.ptc_set_interleave(self._ctx, int(rank), int(nranks), int(block_rows)))
+        h = self._resolution[1]
+        blocks = (h + block_rows - 1) // block_rows
+        rows = sum(min(block_rows, h - gb * block_rows) for gb in range(rank, blocks, nranks))
+        self._rows = (0, rows)
+
     def pixel_count(self):
         return (self._rows[1] - self._rows[0]) * self._resolution[0]
 

@@ -169,6 +169,11 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height);
 /* Render only image rows [row_begin,row_end) of the width x height frame (multi-GPU row bands;
  * no reference equivalent).  Must follow ptc_resize.  Default: all rows. */
 int ptc_set_rows(ptc_ctx* ctx, uint32_t row_begin, uint32_t row_end);
+/* Load-balanced multi-GPU partition: the frame is cut into blocks of block_rows rows dealt round-robin to
+ * nranks contexts; this context renders the blocks rank, rank+nranks, ...  Its framebuffers (ptc_download,
+ * ptc_present_rgba8) hold those rows packed in order.  Slot numbering is per context ("local"), so the noise
+ * pattern differs from the single-context image; contiguous bands (ptc_set_rows) keep the exact option. */
+int ptc_set_interleave(ptc_ctx* ctx, uint32_t rank, uint32_t nranks, uint32_t block_rows);
 int ptc_restart(ptc_ctx* ctx);                                      /* PathTracer::restart, path_tracer.cu:522-525 */
 int ptc_iteration(const ptc_ctx* ctx);                              /* PathTracer::iteration(), path_tracer.hpp:88 */
 int ptc_set_iteration(ptc_ctx* ctx, int iteration);                 /* test hook: continue from a given sample index */
