@@ -200,6 +200,7 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      framebuffer in iteration order (default 8; 1 = strictly serial on the context's
  *                      stream; set before ptc_resize)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
+ *   "leaf_batch"       lanes that must hold an untested leaf before the triangle tests run (default 1)
  *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
