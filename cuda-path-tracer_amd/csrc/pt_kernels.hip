@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
       const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
       const f3 od = normalize(xform_vector(obj->inv_m, rd));
       float en, ef;
-      if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef), 0)) {
+      if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u, 0)) {
         slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
         best_k = -2;
       }
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
           const f3 od = v * (1.0f / scale);
           oo = xform_point(obj->inv_m, ro);
           inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow, 0)) {
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow == 1u, 0)) {
             slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
             wrote = true;
             go = false;
@@ -1229,7 +1229,7 @@ void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
           const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
           const f3 od = normalize(xform_vector(obj->inv_m, rd));
           float en, ef;
-          if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef), 0)) {
+          if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u, 0)) {
             slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
             best_k = -2;
           }
@@ -1272,7 +1272,7 @@ void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
           const f3 od = v * (1.0f / scale);
           oo = xform_point(obj->inv_m, ro);
           inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow, 0)) {
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow == 1u, 0)) {
             // degenerate direction (0/0 in the reference's slab test voids the nesting argument):
             // set aside for k_slow_rays, which walks the tree in the reference's own order
             slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
@@ -1316,7 +1316,7 @@ void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
             const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
             const f3 od = normalize(xform_vector(obj->inv_m, rd));
             float en, ef;
-            if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef), 0)) {
+            if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u, 0)) {
               slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
               best_k = -2;
             }

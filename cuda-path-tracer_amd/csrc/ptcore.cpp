@@ -102,7 +102,7 @@ struct ptc_ctx {
   uint32_t traverse_waves = 6144;
   uint32_t refill_lanes = 20;
   uint32_t leaf_batch = 1;  // measured: batching the triangle tests (8..48 lanes) delays the hit that prunes the rest of the walk and loses 5-30 %
-  bool force_slow = false;
+  int force_slow = 0;
 
   // measurement
   bool time_trace = false;
@@ -442,7 +442,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.bvh4_root = w4.root_ref;
   d.refill_lanes = ctx->refill_lanes;
   d.leaf_batch = ctx->leaf_batch;
-  d.force_slow = ctx->force_slow ? 1u : 0u;
+  d.force_slow = (uint32_t)ctx->force_slow;
   d.spill = nullptr;
   d.spill_stride = ctx->traverse_waves * kWave;
   // stack need: one entry per level of the two-wide tree, up to three per level of the four-wide collapse;
@@ -635,8 +635,8 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     return PTC_OK;
   }
   if (std::strcmp(name, "debug_force_slow") == 0) {
-    ctx->scene.force_slow = value ? 1u : 0u;
-    ctx->force_slow = value != 0;
+    ctx->scene.force_slow = (uint32_t)value;  // 1: every ray at fetch time, 2: every winner at verification time
+    ctx->force_slow = value;
     return PTC_OK;
   }
   if (std::strcmp(name, "leaf_batch") == 0) {

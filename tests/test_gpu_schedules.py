@@ -64,8 +64,10 @@ def test_degenerate_ray_fallback_kernel(pkg, small_scenes):
     scene, w, h = small_scenes["instances"]
     flat = scene.build_scene()
     base = frames(pkg, scene, flat, w, h, 2, 6, variant=0, fif=1)
-    got = frames(pkg, scene, flat, w, h, 2, 6, variant=4, fif=2, params=(("debug_force_slow", 1),))
-    assert same(got, base)
+    for variant in (3, 4):
+        for mode in (1, 2):   # 1: every ray set aside when fetched; 2: every winner fails its verification
+            got = frames(pkg, scene, flat, w, h, 2, 6, variant=variant, fif=2, params=(("debug_force_slow", mode),))
+            assert same(got, base), (variant, mode)
 
 
 def test_axis_aligned_rays(pkg, orc):
