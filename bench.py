@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# Frames in flight run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4), and streams that share a queue serialise.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,6 +51,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
+    ap.add_argument("--frames-in-flight", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
@@ -92,6 +97,10 @@ def main():
     rank_rows = pkg.bands.interleaved_rows(H, world, BLOCK_ROWS)
 
     pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+    pt.set_param("frames_in_flight", args.frames_in_flight)
+    # persistent traversal wavefronts per launch: enough to fill the GPU once per frame in flight; a rank that owns
+    # 1/N of the rows launches proportionally fewer
+    pt.set_param("traverse_waves", max(1024, 6144 // world))
     pt.create_buffers((W, H), flat)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
@@ -221,7 +230,7 @@ def main():
             "config": {"workload": f"config 3: procedural {len(flat.indices) // 3}-triangle heightfield + 3 spheres, "
                                    f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
                        "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
-                       "resolution": [W, H], "max_bounces": MB, "rays_per_step": round(rays / args.steps),
+                       "resolution": [W, H], "max_bounces": MB, "frames_in_flight": args.frames_in_flight, "rays_per_step": round(rays / args.steps),
                        "live_per_bounce_last_frame_rank0": last_live, "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks",
                        "bvh_build_s": round(bvh_build_s, 3)},
             "roofline": roofline,

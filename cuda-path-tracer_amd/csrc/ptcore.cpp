@@ -68,7 +68,7 @@ struct ptc_ctx {
     int bounces_done = 0;
   };
   std::vector<FrameSlot> slots;
-  int frames_in_flight = 8;
+  int frames_in_flight = 16;
   int active_slot = -1;          // slot of the frame being built by ptc_trace_begin/bounce/end
   int last_slot = 0;             // slot of the most recent finished frame
   hipEvent_t order_event = nullptr;  // last accumulate enqueued (accumulates run in iteration order)
@@ -652,7 +652,7 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     return PTC_OK;
   }
   if (std::strcmp(name, "frames_in_flight") == 0) {
-    if (value < 1 || value > 16) return fail(ctx, PTC_ERR_INVALID, "frames_in_flight must be in [1,16]");
+    if (value < 1 || value > 64) return fail(ctx, PTC_ERR_INVALID, "frames_in_flight must be in [1,64]");
     if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set frames_in_flight before ptc_resize");
     ctx->frames_in_flight = value;
     return PTC_OK;

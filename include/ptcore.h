@@ -197,8 +197,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
 /* Tuning knobs (speed only, never results).  Known names:
  *   "traverse_waves"   persistent wavefronts launched per traversal segment (default 4096; before ptc_upload_scene)
  *   "frames_in_flight" consecutive iterations traced concurrently on separate streams, folded into the
- *                      framebuffer in iteration order (default 8; 1 = strictly serial on the context's
- *                      stream; set before ptc_resize)
+ *                      framebuffer in iteration order (default 16; 1 = strictly serial on the context's
+ *                      stream; set before ptc_resize).  ROCm runs streams on GPU_MAX_HW_QUEUES hardware
+ *                      queues (default 4): export GPU_MAX_HW_QUEUES=16 to let them all overlap
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "leaf_batch"       lanes that must hold an untested leaf before the triangle tests run (default 1)
  *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
