@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 // taken dynamically from one cursor per region (own 128-byte line) so that wavefronts that finish early keep
 // the others' tail short; a wavefront whose region is used up moves on to the next one.
 struct RayFeed {
-  uint32_t n, region_size, waves_per_region, home, region, tried, stat_next;
+  uint32_t n, region_size, waves_per_region, home, region, tried, stat_next, static_eighths, dyn_batch;
   uint32_t* cursors;  // [8][32]
   bool in_static;
 
@@ -692,17 +692,25 @@ struct RayFeed {
     const uint32_t b = r * region_size;
     return b < n ? min(n - b, region_size) : 0u;
   }
-  __device__ __forceinline__ uint32_t static_batches(uint32_t r) const { return ((region_len(r) + kWave - 1u) / kWave) * 7u / 8u; }
-  __device__ __forceinline__ void init(uint32_t n_, uint32_t* cursors_)
+  __device__ __forceinline__ uint32_t static_batches(uint32_t r) const
+  {
+    return ((region_len(r) + kWave - 1u) / kWave) * static_eighths / 8u;
+  }
+  // static_eighths: share of every region that is dealt statically (0..8).  Static dealing costs no atomics
+  // but cannot balance regions of different cost (sky rows vs terrain rows in the primary bounce).
+  __device__ __forceinline__ void init(uint32_t n_, uint32_t* cursors_, uint32_t static_eighths_)
   {
     n = n_;
     cursors = cursors_;
+    static_eighths = static_eighths_;
     region_size = ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave;
     waves_per_region = (gridDim.x + 7u) / 8u;
     home = region = blockIdx.x & 7u;
     stat_next = blockIdx.x >> 3;
     tried = 0u;
-    in_static = true;
+    in_static = static_eighths != 0u;
+    // dynamic batches: one atomic hands out this many rays (a cursor line sustains ~30 atomics/us)
+    dyn_batch = n / gridDim.x >= 256u ? 128u : (uint32_t)kWave;
   }
   __device__ __forceinline__ bool exhausted() const { return !in_static && tried >= 8u; }
   // wave-uniform: next batch [begin, end) or false
@@ -723,11 +731,11 @@ struct RayFeed {
       uint32_t base = len;
       if (threadIdx.x == 0u && first < len &&
           first + __hip_atomic_load(&cursors[region * 32u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len)
-        base = first + atomicAdd(&cursors[region * 32u], (uint32_t)kWave);
+        base = first + atomicAdd(&cursors[region * 32u], dyn_batch);
       base = __builtin_amdgcn_readfirstlane(base);
       if (base < len) {
         begin = region * region_size + base;
-        end = region * region_size + min(len, base + kWave);
+        end = region * region_size + min(len, base + dyn_batch);
         return true;
       }
       region = (region + 1u) & 7u;
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
   if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
   RayFeed feed;
-  feed.init(n, &counters->work[work_slot][0][0]);
+  feed.init(n, &counters->work[work_slot][0][0], sc.static_eighths);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;
@@ -945,7 +953,7 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
   if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
   RayFeed feed;
-  feed.init(n, &counters->work[work_slot][0][0]);
+  feed.init(n, &counters->work[work_slot][0][0], sc.static_eighths);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;
@@ -1200,7 +1208,7 @@ void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
   if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
   RayFeed feed;
-  feed.init(n, &counters->work[work_slot][0][0]);
+  feed.init(n, &counters->work[work_slot][0][0], sc.static_eighths);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;

@@ -101,6 +101,7 @@ struct ptc_ctx {
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
   uint32_t traverse_waves = 6144;
   uint32_t refill_lanes = 20;
+  uint32_t static_eighths = 7;
   uint32_t leaf_batch = 1;  // measured: batching the triangle tests (8..48 lanes) delays the hit that prunes the rest of the walk and loses 5-30 %
   int force_slow = 0;
 
@@ -442,6 +443,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.bvh4_root = w4.root_ref;
   d.refill_lanes = ctx->refill_lanes;
   d.leaf_batch = ctx->leaf_batch;
+  d.static_eighths = ctx->static_eighths;
   d.force_slow = (uint32_t)ctx->force_slow;
   d.spill = nullptr;
   d.spill_stride = ctx->traverse_waves * kWave;
@@ -637,6 +639,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (std::strcmp(name, "debug_force_slow") == 0) {
     ctx->scene.force_slow = (uint32_t)value;  // 1: every ray at fetch time, 2: every winner at verification time
     ctx->force_slow = value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "static_eighths") == 0) {
+    if (value < 0 || value > 8) return fail(ctx, PTC_ERR_INVALID, "static_eighths must be in [0,8]");
+    ctx->static_eighths = (uint32_t)value;
+    ctx->scene.static_eighths = ctx->static_eighths;
     return PTC_OK;
   }
   if (std::strcmp(name, "leaf_batch") == 0) {
