@@ -29,9 +29,10 @@ import os
 import sys
 import time
 
-# Frames in flight run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
-# (default 4), and streams that share a queue serialise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Batches of frames run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4), and streams that share a queue serialise.  Must be set before the HIP runtime initialises
+# (torch starts it here, before libptcore.so gets the chance to ask).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np
 
@@ -45,13 +46,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
-    ap.add_argument("--frames-in-flight", type=int, default=16)
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 8 streams x the batch size")
+    ap.add_argument("--batch-frames", type=int, default=0,
+                    help="frames traced per launch; 0 = min(8, steps / 8) so that the timed steps fill 8 streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
@@ -97,10 +100,16 @@ def main():
     rank_rows = pkg.bands.interleaved_rows(H, world, BLOCK_ROWS)
 
     pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+    # Schedule: `batch` consecutive frames share every launch (the latency tail of a bounce -- a few long rays --
+    # is paid once per batch) and 8 batches are in flight on 8 streams (the hardware overlaps about four kernels;
+    # the rest keep its queues fed).  Results do not depend on it (tests/test_gpu_schedules.py).
+    batch = args.batch_frames or max(1, min(8, args.steps // 8))
+    args.batch_frames = batch
+    args.frames_in_flight = args.frames_in_flight or 8 * batch
     pt.set_param("frames_in_flight", args.frames_in_flight)
-    # persistent traversal wavefronts per launch: enough to fill the GPU once per frame in flight; a rank that owns
-    # 1/N of the rows launches proportionally fewer
-    pt.set_param("traverse_waves", max(1024, 6144 // world))
+    pt.set_param("batch_frames", batch)
+    # persistent traversal wavefronts per launch: 8 per CU; with ~4 launches executing at once the GPU is full
+    pt.set_param("traverse_waves", 2048)
     pt.create_buffers((W, H), flat)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
@@ -196,7 +205,7 @@ def main():
     # the wall time of the timed region.
     achieved_chip = alg_bytes / elapsed / 1e9
     roofline = {
-        "bound": "hbm", "kernel": "k_traverse (closest hit, persistent wavefronts)", "achieved": round(achieved, 2),
+        "bound": "hbm", "kernel": "k_traverse4 (closest hit: persistent wavefronts over the 4-wide BVH, %d frames per launch)" % args.batch_frames, "achieved": round(achieved, 2),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "launches": launches, "avg_launch_us": round(trace_ms * 1e3 / max(launches, 1), 2),
         "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
@@ -230,7 +239,7 @@ def main():
             "config": {"workload": f"config 3: procedural {len(flat.indices) // 3}-triangle heightfield + 3 spheres, "
                                    f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
                        "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
-                       "resolution": [W, H], "max_bounces": MB, "frames_in_flight": args.frames_in_flight, "rays_per_step": round(rays / args.steps),
+                       "resolution": [W, H], "max_bounces": MB, "frames_in_flight": args.frames_in_flight, "frames_per_launch": args.batch_frames, "rays_per_step": round(rays / args.steps),
                        "live_per_bounce_last_frame_rank0": last_live, "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks",
                        "bvh_build_s": round(bvh_build_s, 3)},
             "roofline": roofline,

@@ -157,12 +157,26 @@ struct DeviceCounters {
   uint32_t work[kWorkSlots][8][32];
 };
 
+// Several iterations ("frames") traced by the same launches: every per-frame array of a slot is one allocation
+// with frame f at element offset f * stride (chunk arrays: f * chunk_stride; counters: f), and the kernels of
+// one bounce cover all frames of the batch (blockIdx.y = frame; the persistent traversal kernel feeds its lanes
+// from all of them).  One launch then carries count times the rays, so the latency tail of a bounce (a few
+// long rays) is paid once per batch instead of once per frame.
+constexpr int kMaxBatch = 16;
+struct DBatchInfo {
+  uint32_t stride, chunk_stride, count, pad;
+  uint32_t iteration[kMaxBatch];
+};
+struct DCameras {
+  DCamera c[kMaxBatch];
+};
+
 struct DDenoise {
   float c_phi, n_phi, p_phi;
 };
 
 // ---- launch interface (implemented in pt_kernels.hip) ----
-void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, DBand band, uint32_t pix_count,
+void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters);
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
@@ -173,19 +187,19 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
 //   launch_traverse one mesh object: persistent wavefronts, each lane fetches the next ray when its own is done
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
                     DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
-                    DeviceCounters* counters);
+                    DeviceCounters* counters, const DBatchInfo& bi);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,
-                     uint32_t* slow_list);
+                     uint32_t* slow_list, const DBatchInfo& bi);
 // rays with a degenerate direction that the persistent kernels set aside: reference-order traversal
 void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                       const uint32_t* slow_list, DeviceCounters* counters);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
-                 DeviceCounters* counters);
+                 DeviceCounters* counters, const DBatchInfo& bi);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
-                  uint32_t iteration, uint32_t acc_iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
-                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters);
-void launch_accumulate(hipStream_t s, uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count);
+                  bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
+                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, const DBatchInfo& bi);
+void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi);
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);

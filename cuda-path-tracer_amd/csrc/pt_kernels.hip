@@ -537,9 +537,16 @@ __device__ __forceinline__ void generate_ray(const DCamera& cam, float fx, float
 // kernels
 // ------------------------------------------------------------------------------------------------
 // raygen_kernel, ray_gen.cu:11-32.  Slot s of this context holds pixel band_pixel(band, s).
-__global__ __launch_bounds__(256) void k_raygen(DCamera cam, uint32_t iteration, DBand band, uint32_t pix_count,
+__global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DBand band, uint32_t pix_count,
                                                 DPaths paths, DeviceCounters* counters)
 {
+  const uint32_t frame = blockIdx.y;  // see DBatchInfo
+  const DCamera& cam = cams.c[frame];
+  const uint32_t iteration = bi.iteration[frame];
+  paths.o4 += (size_t)frame * bi.stride;
+  paths.d4 += (size_t)frame * bi.stride;
+  paths.t4 += (size_t)frame * bi.stride;
+  counters += frame;
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   if (s == 0u) {
     counters->live[0] = pix_count;
@@ -745,6 +752,108 @@ struct RayFeed {
   }
 };
 
+// RayFeed for a batch of frames (DBatchInfo): count x 8 regions, region (f, r) = eighth r of frame f's live
+// rays, its cursor on frame f's counters.  A wavefront's home keeps the XCD <-> image-region pairing of
+// RayFeed (r = blockIdx & 7) and deals the frames round-robin over the wavefronts of that XCD.  Ranges are
+// returned as batch-global slots (f * stride + slot).  When its static share is done a wavefront looks at
+// all regions at once -- lane p probes the p-th region in its preference order (same eighth of the other
+// frames first: same part of the tree in this XCD's L2) -- and takes from the first that has rays left.
+struct BatchFeed {
+  DeviceCounters* ctr;
+  uint32_t stride, count, bounce, work_slot, static_eighths, dyn_batch;
+  uint32_t home_f, home_r, home_base, stat_next, stat_step, stat_count;
+  bool in_static, done;
+
+  static __device__ __forceinline__ uint32_t region_size_of(uint32_t n) { return ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave; }
+  static __device__ __forceinline__ uint32_t region_len_of(uint32_t n, uint32_t rs, uint32_t r)
+  {
+    const uint32_t b = r * rs;
+    return b < n ? min(n - b, rs) : 0u;
+  }
+  __device__ __forceinline__ uint32_t static_batches_of(uint32_t len) const
+  {
+    return ((len + kWave - 1u) / kWave) * static_eighths / 8u;
+  }
+  __device__ __forceinline__ void init(DeviceCounters* ctr_, const DBatchInfo& bi, int bounce_, int work_slot_,
+                                       uint32_t static_eighths_)
+  {
+    ctr = ctr_;
+    stride = bi.stride;
+    count = bi.count;
+    bounce = (uint32_t)bounce_;
+    work_slot = (uint32_t)work_slot_;
+    // every home needs at least one wavefront for its static share
+    static_eighths = gridDim.x >= 8u * count ? static_eighths_ : 0u;
+    const uint32_t j = blockIdx.x >> 3;
+    home_r = blockIdx.x & 7u;
+    home_f = j % count;
+    const uint32_t with_r = (gridDim.x - home_r + 7u) / 8u;  // wavefronts of this r
+    stat_step = (with_r - home_f + count - 1u) / count;      // ... of which this many share the home
+    stat_next = j / count;
+    const uint32_t n = ctr[home_f].live[bounce];
+    const uint32_t rs = region_size_of(n);
+    stat_count = static_batches_of(region_len_of(n, rs, home_r));
+    home_base = home_f * stride + home_r * rs;
+    in_static = static_eighths != 0u;
+    done = false;
+    // dynamic batches: one atomic hands out this many rays (a cursor line sustains ~30 atomics/us)
+    dyn_batch = (uint64_t)n * count / gridDim.x >= 256u ? 128u : (uint32_t)kWave;
+  }
+  __device__ __forceinline__ bool exhausted() const { return !in_static && done; }
+  // wave-uniform: next batch [begin, end) of batch-global slots, or false
+  __device__ __forceinline__ bool acquire(uint32_t& begin, uint32_t& end)
+  {
+    if (in_static) {
+      if (stat_next < stat_count) {
+        begin = home_base + stat_next * kWave;
+        end = begin + kWave;  // static batches are full batches inside the region
+        stat_next += stat_step;
+        return true;
+      }
+      in_static = false;
+    }
+    while (!done) {
+      bool any = false;
+      for (uint32_t first_p = 0u; first_p < 8u * count; first_p += (uint32_t)kWave) {
+        const uint32_t p = first_p + threadIdx.x;
+        bool has = false;
+        uint32_t len = 0u, first = 0u, gbase = 0u;
+        uint32_t* cursor = nullptr;
+        if (p < 8u * count) {
+          const uint32_t df = p % count, dr = p / count;
+          uint32_t f = home_f + df;
+          if (f >= count) f -= count;
+          const uint32_t r = (home_r + dr) & 7u;
+          const uint32_t n = ctr[f].live[bounce];
+          const uint32_t rs = region_size_of(n);
+          len = region_len_of(n, rs, r);
+          first = static_batches_of(len) * kWave;
+          gbase = f * stride + r * rs;
+          cursor = &ctr[f].work[work_slot][r][0];
+          has = first < len && first + __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len;
+        }
+        const uint64_t mask = __ballot(has);
+        if (mask == 0ull) continue;
+        any = true;
+        const int sel = __ffsll((unsigned long long)mask) - 1;
+        uint32_t base = len;
+        if ((int)threadIdx.x == sel) base = first + atomicAdd(cursor, dyn_batch);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)base, sel);
+        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, sel);
+        const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gbase, sel);
+        if (b < l) {
+          begin = g + b;
+          end = g + min(l, b + dyn_batch);
+          return true;
+        }
+        break;  // another wavefront took the rest of that region: look again
+      }
+      if (!any) done = true;
+    }
+    return false;
+  }
+};
+
 constexpr uint32_t kRefillLanes = 20u;  // fetch new rays once this many lanes are idle
 
 template <bool kCount, bool kFirst>
@@ -937,23 +1046,35 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
 // ------------------------------------------------------------------------------------------------
 // Conservative FMA slabs on four children per step, children visited nearest first, optimistic acceptance,
 // one exact test of the winner's parent box (see variant 4 below for the argument), results in batches.
-constexpr int kLds4 = 24;  // traversal stack entries per lane in LDS (6 KiB per wavefront); deeper: DScene::spill
+#ifndef PT_T4_LDS
+#define PT_T4_LDS 24
+#endif
+#ifndef PT_T4_WAVES
+#define PT_T4_WAVES 5
+#endif
+constexpr int kLds4 = PT_T4_LDS;  // traversal stack entries per lane in LDS (6 KiB per wavefront); deeper: DScene::spill
 
 template <bool kCount, bool kFirst>
-__global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
-                                                     int work_slot, DeviceCounters* counters, uint32_t* slow_list)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES))) void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
+                                                     int work_slot, DeviceCounters* counters, uint32_t* slow_list,
+                                                     DBatchInfo bi)
 {
   __shared__ uint32_t s_stack[kLds4 * kWave];
   uint32_t* stack = s_stack + threadIdx.x;
   const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
-  const uint32_t n = counters->live[bounce];
-  if (n == 0u) return;
+  // `slot` below is batch-global (frame * bi.stride + slot in the frame); flags, the slow-ray list and the
+  // test tallies of the whole batch go to frame 0's counters
+  uint32_t n_max = 0u;
+  for (uint32_t f = 0; f < bi.count; ++f) n_max = max(n_max, counters[f].live[bounce]);
+  if (n_max == 0u) return;
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
-  if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
-  RayFeed feed;
-  feed.init(n, &counters->work[work_slot][0][0], sc.static_eighths);
+  const char* node_bytes = reinterpret_cast<const char*>(sc.bvh4);
+  // more wavefronts than batches (the margin keeps every wavefront that owns a static batch, see BatchFeed)
+  if (blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
+  BatchFeed feed;
+  feed.init(counters, bi, bounce, work_slot, sc.static_eighths);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;
@@ -963,7 +1084,10 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
   int sp = 0, best_k = -1;
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
-  bool neg_x = false, neg_y = false, neg_z = false;
+  // byte offsets of the near plane of each axis inside a node (lo_x 0, lo_y 16, lo_z 32, hi = lo + 48); the
+  // far plane's offset is the near one ^ kFarX/Y/Z
+  uint32_t near_x = 0u, near_y = 16u, near_z = 32u;
+  constexpr uint32_t kFarX = 0u ^ 48u, kFarY = 16u ^ 64u, kFarZ = 32u ^ 80u;
   float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
   Tally tally;
   uint32_t ray_boxes = 0u;
@@ -977,14 +1101,52 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
     }
     ++sp;
   };
+  auto pop = [&]() -> uint32_t {
+    if (sp == 0) return kNoChild;
+    --sp;
+    uint32_t r = stack[min(sp, kLds4 - 1) * kWave];
+    if (__builtin_expect(sp >= kLds4, 0)) r = sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x;
+    return r;
+  };
+  // the conservative slab pair of one box for this lane's ray, tolerance folded INWARDS: if even that interval is
+  // non-empty, the reference's exact test of the box passes
+  auto surely_inside = [&](const f3 lo, const f3 hi) -> bool {
+    const bool nx = near_x != 0u, ny = near_y != 16u, nz = near_z != 32u;
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(nx ? hi.x : lo.x, inv.x, oif.x), __builtin_fmaf(ny ? hi.y : lo.y, inv.y, oif.y)),
+                           __builtin_fmaf(nz ? hi.z : lo.z, inv.z, oif.z));
+    const float tf = fminf(fminf(__builtin_fmaf(nx ? lo.x : hi.x, inv.x, oin.x), __builtin_fmaf(ny ? lo.y : hi.y, inv.y, oin.y)),
+                           __builtin_fmaf(nz ? lo.z : hi.z, inv.z, oin.z));
+    return tf >= tn;
+  };
+  // Result of a finished ray.  The winner is the closest of ALL candidates; it is the reference's answer iff the
+  // reference reaches it: the object's world box passes (path_tracer.cu:84, tested here instead of before the
+  // walk) and the box of the winner's parent passes the reference's own test (nesting).  Both tests have a
+  // cheap sufficient form (approximate arithmetic with the error bound held against the ray); the exact
+  // divisions run only for rays that graze a box.
   auto finalize = [&]() {
     if (best_k >= 0) {
+      // world box (ray_aabb, intersections.cuh:87-103): quotients by reciprocal, each within 3 ulp of the quotient
+      const f3 bmin = ld3(obj->bmin), bmax = ld3(obj->bmax);
+      const f3 winv = mk3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+      const f3 a0 = (bmin - ro) * winv, a1 = (bmax - ro) * winv;
+      const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+      const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+      const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
+      bool world_sure = box_ok && finite_f(winv.x + winv.y + winv.z) && (wf - wn) > 2e-6f * (fabsf(wf) + fabsf(wn));
       const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
-      const f3 od = normalize(xform_vector(obj->inv_m, rd));
-      float en, ef;
-      if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u, 0)) {
-        slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
-        best_k = -2;
+      const bool parent_sure = surely_inside(xyz(pb0), xyz(pb1));
+      if (__builtin_expect(!(world_sure && parent_sure) || sc.force_slow == 2u, 0)) {
+        if (!ray_aabb(ro, rd, bmin, bmax)) {
+          best_k = -1;  // the reference skips the object: the carried hit (or the miss) stands
+        } else {
+          const f3 od = normalize(xform_vector(obj->inv_m, rd));
+          float en, ef;
+          if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u) {
+            // a ray grazing the parent's box within rounding: redone in the reference's order by k_slow_rays
+            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+            best_k = -2;
+          }
+        }
       }
     }
     if (best_k >= 0) {
@@ -1026,31 +1188,43 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
           const float carried = hits.tp[slot].x;
           if (carried >= 0.0f) t_in = carried;
         }
-        bool go = sc.bvh_node_count != 0u && ray_aabb(ro, rd, ld3(obj->bmin), ld3(obj->bmax));  // path_tracer.cu:84
+        bool go = sc.bvh_node_count != 0u;
         bool wrote = false;
         if (go) {
-          const f3 v = xform_vector(obj->inv_m, rd);  // inverse_transform_ray, transform.hpp:51-58
-          scale = ieee_sqrt(dot(v, v));
-          const f3 od = v * (1.0f / scale);
+          // inverse_transform_ray (transform.hpp:51-58) for the walk only: the walk has to be conservative, not
+          // exact, so the normalisation and the reciprocals are the hardware approximations (1 ulp) and the
+          // error bound below covers them; everything that decides the result is recomputed exactly in finalize
+          const f3 v = xform_vector(obj->inv_m, rd);
+          const float len2 = dot(v, v);
+          const float rlen = __builtin_amdgcn_rsqf(len2);
+          scale = len2 * rlen;
+          const f3 od = v * rlen;
           oo = xform_point(obj->inv_m, ro);
-          inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow == 1u, 0)) {
+          inv = mk3(__builtin_amdgcn_rcpf(od.x), __builtin_amdgcn_rcpf(od.y), __builtin_amdgcn_rcpf(od.z));
+          // Slab form t = fma(b, 1/d, -o/d).  Against the reference's (b - o)/d (d normalised with IEEE sqrt and
+          // divide) it is off by at most ~1e-6 of |b/d| + |o/d| per axis (rsq, rcp: 1 ulp each, three roundings);
+          // four times that bound (|b| <= the root box) is folded into the two origin terms so the near side
+          // can only move nearer and the far side farther.
+          const f3 oi = mk3(-(oo.x * inv.x), -(oo.y * inv.y), -(oo.z * inv.z));
+          const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
+          const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
+          const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
+          const f3 tol = mk3(4e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
+                             4e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
+                             4e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z) && finite_f(tol.x + tol.y + tol.z)) ||
+                               sc.force_slow == 1u, 0)) {
+            // degenerate direction (0/0 or overflow in the slab terms voids the error bound): set aside for
+            // k_slow_rays, which walks the tree in the reference's own order
             slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
             wrote = true;
             go = false;
           } else {
-            const f3 oi = mk3(-(oo.x * inv.x), -(oo.y * inv.y), -(oo.z * inv.z));
-            const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
-            const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
-            const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
-            const f3 tol = mk3(1e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
-                               1e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
-                               1e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
             oin = oi - tol;
             oif = oi + tol;
-            neg_x = inv.x < 0.0f;
-            neg_y = inv.y < 0.0f;
-            neg_z = inv.z < 0.0f;
+            near_x = inv.x < 0.0f ? 48u : 0u;
+            near_y = inv.y < 0.0f ? 64u : 16u;
+            near_z = inv.z < 0.0f ? 80u : 32u;
             best_t = t_in;
             best_k = -1;
             limit = scale * best_t;
@@ -1080,35 +1254,34 @@ __global__ __launch_bounds__(kWave) void k_traverse4(DScene sc, uint32_t obj_ind
     // else can proceed).  Measured on the 1M-triangle scene: a threshold of 1 (test at once) is fastest --
     // the triangle code then runs nearly every iteration with ~1/8 of the lanes, but batching 8..48 lanes
     // delays the hit that prunes the rest of the walk and costs 5-30 %.
-    auto pop = [&]() -> uint32_t {
-      if (sp == 0) return kNoChild;
-      --sp;
-      return sp < kLds4 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x;
-    };
     if (active && cur != kNoChild && (cur & kLeafBit) && pend == kNoChild) {
       pend = cur;
       cur = pop();
     }
     if (active && cur != kNoChild && !(cur & kLeafBit)) {
-      const float4* q = sc.bvh4 + 8u * (size_t)cur;
-      const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5], rf = q[6];
-      // near / far plane of each axis by the sign of 1/d; one FMA per plane
-      const float4 nx = neg_x ? mxx : mnx, fx = neg_x ? mnx : mxx;
-      const float4 ny = neg_y ? mxy : mny, fy = neg_y ? mny : mxy;
-      const float4 nz = neg_z ? mxz : mnz, fz = neg_z ? mnz : mxz;
+      // near / far plane of each axis straight from its place in the node (chosen by the sign of 1/d)
+      const uint32_t nb = cur << 7;
+      const float4 nx = *reinterpret_cast<const float4*>(node_bytes + (nb | near_x));
+      const float4 ny = *reinterpret_cast<const float4*>(node_bytes + (nb | near_y));
+      const float4 nz = *reinterpret_cast<const float4*>(node_bytes + (nb | near_z));
+      const float4 fx = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_x) ^ kFarX));
+      const float4 fy = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_y) ^ kFarY));
+      const float4 fz = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_z) ^ kFarZ));
+      const float4 rf = *reinterpret_cast<const float4*>(node_bytes + (nb | 96u));
       float key[4];
       uint32_t ref[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
       const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, nya[4] = {ny.x, ny.y, ny.z, ny.w}, nza[4] = {nz.x, nz.y, nz.z, nz.w};
       const float fxa[4] = {fx.x, fx.y, fx.z, fx.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        // an unused child slot holds the empty box (+inf, -inf): its near value is +inf, it is never taken
         const float tn = fmaxf(fmaxf(__builtin_fmaf(nxa[c], inv.x, oin.x), __builtin_fmaf(nya[c], inv.y, oin.y)),
                                __builtin_fmaf(nza[c], inv.z, oin.z));
         const float tf = fminf(fminf(__builtin_fmaf(fxa[c], inv.x, oif.x), __builtin_fmaf(fya[c], inv.y, oif.y)),
                                __builtin_fmaf(fza[c], inv.z, oif.z));
-        const bool valid = ref[c] != kNoChild;
-        const bool go = valid && !((tf - tn) < -1e-4f * (fabsf(tn) + fabsf(tf))) && !box_culled(tn, tf, limit);
-        if (kCount && valid) { ++tally.boxes; ++ray_boxes; }
+        const bool miss = (tf - tn) < -1e-4f * (fabsf(tn) + fabsf(tf));
+        const bool go = !(miss | box_culled(tn, tf, limit));
+        if (kCount && ref[c] != kNoChild) { ++tally.boxes; ++ray_boxes; }
         key[c] = go ? tn : __builtin_inff();
       }
       // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
@@ -1486,8 +1659,15 @@ __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_ind
 // path_tracer.cu:78-100), continuing from / handing on the closest hit in the hit record.
 template <bool kFirst, bool kLast>
 __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
-                                                 int bounce, uint32_t* chunk_counts, DeviceCounters* counters)
+                                                 int bounce, uint32_t* chunk_counts, DeviceCounters* counters, DBatchInfo bi)
 {
+  const uint32_t frame = blockIdx.y;  // see DBatchInfo
+  paths.o4 += (size_t)frame * bi.stride;
+  paths.d4 += (size_t)frame * bi.stride;
+  hits.tp += (size_t)frame * bi.stride;
+  hits.nm += (size_t)frame * bi.stride;
+  chunk_counts += (size_t)frame * bi.chunk_stride;
+  counters += frame;
   const uint32_t n = counters->live[bounce];
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   if (blockIdx.x * 256u >= n) return;
@@ -1540,10 +1720,14 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
 // Exclusive scan of the per-chunk live counts (one workgroup; <= ~32k chunks at 1080p).
 // Writes live[bounce+1] (0 after the last bounce: nothing survives the cap) and the ray counter.
 __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, const uint32_t* chunk_counts,
-                                               uint32_t* chunk_offsets, DeviceCounters* counters)
+                                               uint32_t* chunk_offsets, DeviceCounters* counters, DBatchInfo bi)
 {
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_carry;
+  const uint32_t frame = blockIdx.x;  // one workgroup per frame of the batch
+  chunk_counts += (size_t)frame * bi.chunk_stride;
+  chunk_offsets += (size_t)frame * bi.chunk_stride;
+  counters += frame;
   const uint32_t n = counters->live[bounce];
   const uint32_t chunks = (n + kChunk - 1u) / kChunk;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1578,14 +1762,30 @@ __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, cons
 
 // material_kernel (path_tracer.cu:292-315) + the stable compaction scatter + the final gather of
 // every path that ends at this bounce.
-// acc_iteration: the sample index used for the running mean into `fb`.  With several frames in flight `fb` is
-// this frame's staging buffer and acc_iteration is 0 (plain store); k_accumulate then folds the staged
-// sample into the real framebuffer in iteration order.
-__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, uint32_t iteration,
-                                               uint32_t acc_iteration, int bounce, int last_bounce,
-                                               const uint32_t* slot_base, const uint32_t* chunk_offsets, DFrame fb,
-                                               DBand band, DeviceCounters* counters)
+// staged: `fb` is the slot's staging buffer (one sample per frame of the batch, plain stores); k_accumulate then
+// folds the staged samples into the real framebuffer in iteration order.  Otherwise the running mean goes
+// straight into `fb`.
+__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, int staged, int bounce,
+                                               int last_bounce, const uint32_t* slot_base, const uint32_t* chunk_offsets,
+                                               DFrame fb, DBand band, DeviceCounters* counters, DBatchInfo bi)
 {
+  const uint32_t frame = blockIdx.y;  // see DBatchInfo
+  const uint32_t iteration = bi.iteration[frame];
+  const uint32_t acc_iteration = staged ? 0u : iteration;
+  in.o4 += (size_t)frame * bi.stride;
+  in.d4 += (size_t)frame * bi.stride;
+  in.t4 += (size_t)frame * bi.stride;
+  out.o4 += (size_t)frame * bi.stride;
+  out.d4 += (size_t)frame * bi.stride;
+  out.t4 += (size_t)frame * bi.stride;
+  hits.tp += (size_t)frame * bi.stride;
+  hits.nm += (size_t)frame * bi.stride;
+  chunk_offsets += (size_t)frame * bi.chunk_stride;
+  if (staged) {
+    fb.color4 += (size_t)frame * bi.stride;
+    fb.nd4 += (size_t)frame * bi.stride;
+  }
+  counters += frame;
   const uint32_t n = counters->live[bounce];
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   if (blockIdx.x * 256u >= n) return;
@@ -1642,14 +1842,17 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 }
 
 
-// final_gather (path_tracer.cu:203-219) of one staged sample into the accumulated framebuffers
-__global__ __launch_bounds__(256) void k_accumulate(uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count)
+// final_gather (path_tracer.cu:203-219) of the batch's staged samples into the accumulated framebuffers, in
+// iteration order (running means do not commute)
+__global__ __launch_bounds__(256) void k_accumulate(DFrame stage, DFrame fb, uint32_t pix_count, DBatchInfo bi)
 {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= pix_count) return;
-  const float4 c = stage.color4[i], g = stage.nd4[i];
-  accumulate_color(fb.color4, i, iteration, mk3(c.x, c.y, c.z));
-  accumulate_nd(fb.nd4, i, iteration, mk3(g.x, g.y, g.z), g.w);
+  for (uint32_t f = 0; f < bi.count; ++f) {
+    const float4 c = stage.color4[(size_t)f * bi.stride + i], g = stage.nd4[(size_t)f * bi.stride + i];
+    accumulate_color(fb.color4, i, bi.iteration[f], mk3(c.x, c.y, c.z));
+    accumulate_nd(fb.nd4, i, bi.iteration[f], mk3(g.x, g.y, g.z), g.w);
+  }
 }
 
 // path_tracing_mega_kernel, path_tracer.cu:227-269: the whole path in one thread, one RNG stream per
@@ -1862,10 +2065,10 @@ __global__ void k_selftest(const float* a, const float* b, uint32_t n, float* ou
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
-void launch_raygen(hipStream_t s, const DCamera& cam, uint32_t iteration, DBand band, uint32_t pix_count,
+void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters)
 {
-  hipLaunchKernelGGL(k_raygen, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, cam, iteration, band, pix_count,
+  hipLaunchKernelGGL(k_raygen, dim3(div_up(pix_count, 256u), bi.count), dim3(256), 0, s, cams, bi, band, pix_count,
                      paths, counters);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
@@ -1888,17 +2091,17 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
 }
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
                     DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
-                    DeviceCounters* counters)
+                    DeviceCounters* counters, const DBatchInfo& bi)
 {
-  const dim3 grid(div_up(max_paths, 256u)), block(256);
+  const dim3 grid(div_up(max_paths, 256u), bi.count), block(256);
   if (first && last)
-    hipLaunchKernelGGL((k_spheres<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+    hipLaunchKernelGGL((k_spheres<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
   else if (first)
-    hipLaunchKernelGGL((k_spheres<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+    hipLaunchKernelGGL((k_spheres<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
   else if (last)
-    hipLaunchKernelGGL((k_spheres<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+    hipLaunchKernelGGL((k_spheres<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
   else
-    hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters);
+    hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
 }
 void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                       const uint32_t* slow_list, DeviceCounters* counters)
@@ -1908,8 +2111,9 @@ void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bo
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,
-                     uint32_t* slow_list)
+                     uint32_t* slow_list, const DBatchInfo& bi)
 {
+  // only variant 3 understands batches of frames (the context enforces bi.count == 1 for the others)
   const dim3 grid(waves), block(kWave);
   if (variant == 4) {
     if (count_tests) {
@@ -1923,11 +2127,11 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
   }
   if (variant == 3) {
     if (count_tests) {
-      if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
-      else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+      if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+      else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
     } else {
-      if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
-      else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
+      if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+      else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
     }
     return;
   }
@@ -1940,21 +2144,21 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
   }
 }
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
-                 DeviceCounters* counters)
+                 DeviceCounters* counters, const DBatchInfo& bi)
 {
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, bounce, last_bounce ? 1 : 0, chunk_counts, chunk_offsets,
-                     counters);
+  hipLaunchKernelGGL(k_scan, dim3(bi.count), dim3(1024), 0, s, bounce, last_bounce ? 1 : 0, chunk_counts, chunk_offsets,
+                     counters, bi);
 }
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
-                  uint32_t iteration, uint32_t acc_iteration, int bounce, bool last_bounce, const uint32_t* slot_base,
-                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters)
+                  bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
+                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, const DBatchInfo& bi)
 {
-  hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u)), dim3(256), 0, s, scene, in, out, hits, iteration,
-                     acc_iteration, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, band, counters);
+  hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u), bi.count), dim3(256), 0, s, scene, in, out, hits,
+                     staged ? 1 : 0, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, band, counters, bi);
 }
-void launch_accumulate(hipStream_t s, uint32_t iteration, DFrame stage, DFrame fb, uint32_t pix_count)
+void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, iteration, stage, fb, pix_count);
+  hipLaunchKernelGGL(k_accumulate, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, stage, fb, pix_count, bi);
 }
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters)

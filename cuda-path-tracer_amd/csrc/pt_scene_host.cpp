@@ -2,6 +2,7 @@
 #include "pt_host.hpp"
 #include "pt_device.hpp"
 
+#include <limits>
 #include <cfloat>
 #include <algorithm>
 #include <cstring>
@@ -245,9 +246,9 @@ struct Collapse {
         }
         refs[k] = emit(kids[k], level + 1u);
       } else {
-        for (int a = 0; a < 3; ++a) {
-          lo[a][k] = 0.0f;
-          hi[a][k] = 0.0f;
+        for (int a = 0; a < 3; ++a) {  // the empty box: every slab test of it fails (k_traverse4)
+          lo[a][k] = std::numeric_limits<float>::infinity();
+          hi[a][k] = -std::numeric_limits<float>::infinity();
         }
         refs[k] = kNoChild;
       }

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,6 +32,14 @@ static_assert(sizeof(ptc_bvh_node) == 32, "BVH node is 32 bytes (bvh.hpp:30)");
 static_assert(PTC_MAX_BOUNCES_CAP == kMaxBounces, "bounce cap mismatch");
 
 static thread_local std::string g_create_error;
+
+// in-flight path state a context allocates when the caller has not chosen frames_in_flight
+constexpr uint64_t kAutoFrameBytes = 24ull << 30;
+
+// The frames in flight run on separate HIP streams, and streams only overlap when they sit on different
+// hardware queues; the runtime's default is 4 queues per process.  Ask for more before the runtime starts
+// (no effect if the application has set the variable or has already initialised HIP).
+__attribute__((constructor)) static void ptc_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 struct ptc_ctx {
   int device = 0;
@@ -61,14 +70,27 @@ struct ptc_ctx {
     uint32_t* chunk_offsets = nullptr;
     uint32_t* slow_list = nullptr;  // slots of rays set aside for k_slow_rays
     DFrame stage{};
-    DeviceCounters* counters = nullptr;
+    DeviceCounters* counters = nullptr;  // one per frame of the batch
     hipEvent_t done = nullptr;  // after this slot's last accumulate
     int cur = 0;
     int work_slot = 0;
     int bounces_done = 0;
+    DBatchInfo bi{};            // the batch being traced / traced last
   };
   std::vector<FrameSlot> slots;
-  int frames_in_flight = 16;
+  int frames_in_flight = 64;
+  bool frames_auto = true;  // not set by the caller: ptc_resize caps it so that the in-flight state stays under kAutoFrameBytes
+  // Batches: up to `batch` consecutive iterations share the launches of a slot (DBatchInfo).  ptc_trace only
+  // queues the iteration; the batch is enqueued when it is full or when anything else looks at the context.
+  int batch_frames = 8;   // requested (ptc_set_param, before ptc_resize)
+  int batch = 1;          // allocated per slot
+  bool staged = false;    // samples go through staging buffers and k_accumulate
+  struct Pending {
+    DCamera cam;
+    uint32_t iteration;
+  };
+  std::vector<Pending> pending;
+  uint64_t batches_issued = 0;
   int active_slot = -1;          // slot of the frame being built by ptc_trace_begin/bounce/end
   int last_slot = 0;             // slot of the most recent finished frame
   hipEvent_t order_event = nullptr;  // last accumulate enqueued (accumulates run in iteration order)
@@ -99,7 +121,7 @@ struct ptc_ctx {
     uint32_t begin, end;  // object range (mesh: one object)
   };
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
-  uint32_t traverse_waves = 6144;
+  uint32_t traverse_waves = 2048;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 7;
   uint32_t leaf_batch = 1;  // measured: batching the triangle tests (8..48 lanes) delays the hit that prunes the rest of the walk and loses 5-30 %
@@ -112,7 +134,7 @@ struct ptc_ctx {
     hipEvent_t start, stop;
     int bounce;
   };
-  bool staging() const { return slots.size() > 1; }
+  bool staging() const { return staged; }
   std::vector<TimedLaunch> timed;        // recorded, not yet read
   std::vector<hipEvent_t> free_events;
   double trace_ms[kMaxBounces] = {};
@@ -246,9 +268,12 @@ uint32_t bvh_depth_of(const ptc_bvh_node* nodes, uint32_t count)
 }
 
 
+int flush_pending(ptc_ctx* ctx);
+
 // wait (host-side) until every frame in flight has been folded into the framebuffers
 int sync_frames(ptc_ctx* ctx)
 {
+  if (int rc = flush_pending(ctx)) return rc;
   for (auto& sl : ctx->slots)
     if (sl.stream) HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -264,6 +289,7 @@ void free_slots(ptc_ctx* ctx)
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
   ctx->slots.clear();
+  ctx->pending.clear();
   ctx->active_slot = -1;
 }
 
@@ -360,7 +386,7 @@ int ptc_set_stream(ptc_ctx* ctx, void* hip_stream)
   if (int rc = bind_device(ctx)) return rc;
   if (int rc = sync_frames(ctx)) return rc;
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
-  if (ctx->slots.size() == 1) ctx->slots[0].stream = ctx->stream;  // one frame in flight: trace on the caller's stream
+  if (!ctx->staged && !ctx->slots.empty()) ctx->slots[0].stream = ctx->stream;  // one frame in flight: trace on the caller's stream
   return PTC_OK;
 }
 
@@ -500,13 +526,24 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   const size_t P = (size_t)width * height;
   auto& pool = ctx->frame_allocs;
   const size_t chunks = (P + kChunk - 1) / kChunk;
-  const int F = std::max(1, ctx->frames_in_flight);
+  int frames = std::max(1, ctx->frames_in_flight);
+  if (ctx->frames_auto) {
+    // path state, hit records, staging: 164 bytes per pixel and frame in flight
+    const uint64_t per_frame = 164ull * P;
+    frames = (int)std::min<uint64_t>((uint64_t)frames, std::max<uint64_t>(1ull, kAutoFrameBytes / per_frame));
+  }
+  const int B = std::min({std::max(1, ctx->batch_frames), frames, kMaxBatch});
+  if (ctx->frames_auto) frames -= frames % B;
+  const int F = (frames + B - 1) / B;  // slots (streams); each holds a batch of B frames
+  ctx->batch = B;
+  ctx->staged = frames > 1;
+  ctx->batches_issued = 0;
   ctx->slots.resize((size_t)F);
   if (int rc = dev_alloc(ctx, pool, &ctx->fb.color4, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->fb.nd4, P)) return rc;
   for (int f = 0; f < F; ++f) {
     auto& sl = ctx->slots[(size_t)f];
-    if (F == 1) {
+    if (!ctx->staged) {
       sl.stream = ctx->stream;
       sl.own_stream = false;
     } else {
@@ -514,23 +551,28 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
       sl.own_stream = true;
     }
     HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    const size_t BP = (size_t)B * P;  // frame f of the batch at element offset f * P (DBatchInfo::stride)
     for (int k = 0; k < 2; ++k) {
-      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].o4, P)) return rc;
-      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].d4, P)) return rc;
-      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].t4, P)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].o4, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].d4, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].t4, BP)) return rc;
     }
-    if (int rc = dev_alloc(ctx, pool, &sl.hits.tp, P)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, P)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, chunks)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, chunks)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &sl.slow_list, P)) return rc;
-    if (int rc = dev_alloc(ctx, pool, &sl.counters, 1)) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(sl.counters, 0, sizeof(DeviceCounters), ctx->stream));
-    if (F == 1) {
+    if (int rc = dev_alloc(ctx, pool, &sl.hits.tp, BP)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, BP)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, (size_t)B * chunks)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, (size_t)B * chunks)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.counters, (size_t)B)) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(sl.counters, 0, sizeof(DeviceCounters) * (size_t)B, ctx->stream));
+    sl.bi = DBatchInfo{};
+    sl.bi.stride = (uint32_t)P;
+    sl.bi.chunk_stride = (uint32_t)chunks;
+    sl.bi.count = 1u;
+    if (!ctx->staged) {
       sl.stage = ctx->fb;  // shade accumulates straight into the framebuffers
     } else {
-      if (int rc = dev_alloc(ctx, pool, &sl.stage.color4, P)) return rc;
-      if (int rc = dev_alloc(ctx, pool, &sl.stage.nd4, P)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.stage.color4, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.stage.nd4, BP)) return rc;
     }
   }
   if (int rc = dev_alloc(ctx, pool, &ctx->den_a, P)) return rc;
@@ -595,6 +637,7 @@ int ptc_iteration(const ptc_ctx* ctx) { return ctx ? ctx->iteration : PTC_ERR_IN
 int ptc_set_iteration(ptc_ctx* ctx, int iteration)
 {
   if (!ctx || iteration < 0) return PTC_ERR_INVALID;
+  if (int rc = flush_pending(ctx)) return rc;
   ctx->iteration = iteration;
   return PTC_OK;
 }
@@ -609,6 +652,8 @@ int ptc_set_max_iterations(ptc_ctx* ctx, int max_iterations)
 int ptc_set_method(ptc_ctx* ctx, int method)
 {
   if (!ctx || (method != PTC_METHOD_MEGAKERNEL && method != PTC_METHOD_STREAMING)) return fail(ctx, PTC_ERR_INVALID, "unknown method");
+  if (method == ctx->method) return PTC_OK;
+  if (int rc = flush_pending(ctx)) return rc;
   ctx->method = method;
   return PTC_OK;
 }
@@ -616,6 +661,8 @@ int ptc_set_method(ptc_ctx* ctx, int method)
 int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 {
   if (!ctx || max_bounces < 1 || max_bounces > (int)kMaxBounces) return fail(ctx, PTC_ERR_INVALID, "max_bounces must be in [1,64]");
+  if (max_bounces == ctx->max_bounces) return PTC_OK;
+  if (int rc = flush_pending(ctx)) return rc;
   ctx->max_bounces = max_bounces;
   return PTC_OK;
 }
@@ -623,6 +670,8 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
   if (!ctx || variant < 0 || variant > 4) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
+  if (variant == ctx->trace_variant) return PTC_OK;
+  if (int rc = flush_pending(ctx)) return rc;
   ctx->trace_variant = variant;
   return PTC_OK;
 }
@@ -630,6 +679,13 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
 {
   if (!ctx || !name) return PTC_ERR_INVALID;
+  if (int rc = flush_pending(ctx)) return rc;
+  if (std::strcmp(name, "batch_frames") == 0) {
+    if (value < 1 || value > kMaxBatch) return fail(ctx, PTC_ERR_INVALID, "batch_frames must be in [1,16]");
+    if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set batch_frames before ptc_resize");
+    ctx->batch_frames = value;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "traverse_waves") == 0) {
     if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "traverse_waves out of range");
     if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set traverse_waves before ptc_upload_scene");
@@ -660,9 +716,10 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     return PTC_OK;
   }
   if (std::strcmp(name, "frames_in_flight") == 0) {
-    if (value < 1 || value > 64) return fail(ctx, PTC_ERR_INVALID, "frames_in_flight must be in [1,64]");
+    if (value < 1 || value > 256) return fail(ctx, PTC_ERR_INVALID, "frames_in_flight must be in [1,256]");
     if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set frames_in_flight before ptc_resize");
     ctx->frames_in_flight = value;
+    ctx->frames_auto = false;
     return PTC_OK;
   }
   return fail(ctx, PTC_ERR_INVALID, std::string("unknown parameter ") + name);
@@ -683,34 +740,36 @@ static int frame_ready(ptc_ctx* ctx)
   return bind_device(ctx);
 }
 
-int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
+namespace {
+
+// Enqueue raygen for `count` consecutive iterations on the next slot (round robin) and make it the active batch.
+int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
 {
-  if (int rc = frame_ready(ctx)) return rc;
-  if (!camera) return fail(ctx, PTC_ERR_INVALID, "camera is NULL");
-  if (ctx->active_slot >= 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_end missing");
-  ctx->cam = make_camera(*camera, ctx->width, ctx->height);
-  ctx->have_cam = true;
-  const int f = ctx->iteration % (int)ctx->slots.size();
+  const int f = (int)(ctx->batches_issued % ctx->slots.size());
   auto& sl = ctx->slots[(size_t)f];
-  // the slot's previous frame has been enqueued on the same stream, so its buffers are free in stream order.
+  // the slot's previous batch has been enqueued on the same stream, so its buffers are free in stream order.
   // A main-stream consumer that still reads the framebuffers (denoise) must finish before anything is folded
-  // in: with staging that is only the accumulate at the end of the frame (so tracing overlaps the denoise of
+  // in: with staging that is only the accumulate at the end of the batch (so tracing overlaps the denoise of
   // the previous frame); without staging the shade kernels write the framebuffers directly.
   if (ctx->main_valid && !ctx->staging()) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
   sl.cur = 0;
   sl.work_slot = 0;
   sl.bounces_done = 0;
-  launch_raygen(sl.stream, ctx->cam, (uint32_t)ctx->iteration, ctx->band, ctx->pix_count, sl.paths[0], sl.counters);
+  sl.bi.count = (uint32_t)count;
+  DCameras cams{};
+  for (int k = 0; k < count; ++k) {
+    cams.c[k] = items[k].cam;
+    sl.bi.iteration[k] = items[k].iteration;
+  }
+  launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters);
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->active_slot = f;
+  ++ctx->batches_issued;
   return PTC_OK;
 }
 
-int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
+int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
 {
-  if (int rc = frame_ready(ctx)) return rc;
-  if (ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
-  if (bounce < 0 || bounce >= ctx->max_bounces) return fail(ctx, PTC_ERR_INVALID, "bounce out of range");
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
   const bool last = bounce == ctx->max_bounces - 1;
   DPaths in = sl.paths[sl.cur], out = sl.paths[sl.cur ^ 1];
@@ -741,18 +800,19 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       const bool first = k == 0, final_seg = k + 1 == ctx->segments.size();
       if (seg.mesh) {
         if (sl.work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
-          HIP_TRY(ctx, hipMemsetAsync(&sl.counters->work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, sl.stream));
+          for (uint32_t fr = 0; fr < sl.bi.count; ++fr)
+            HIP_TRY(ctx, hipMemsetAsync(&sl.counters[fr].work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, sl.stream));
           sl.work_slot = 0;
         }
         ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
         if (int rc = timed_begin(tl)) return rc;
         launch_traverse(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
-                        ctx->count_tests, ctx->traverse_waves, ctx->trace_variant, sl.slow_list);
+                        ctx->count_tests, ctx->traverse_waves, ctx->trace_variant, sl.slow_list, sl.bi);
         if (int rc = timed_end(tl)) return rc;
         if (ctx->trace_variant >= 3) launch_slow_rays(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters);
       } else {
         launch_spheres(sl.stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
-                       sl.chunk_counts, sl.counters);
+                       sl.chunk_counts, sl.counters, sl.bi);
       }
     }
   } else {
@@ -762,25 +822,22 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
                  ctx->count_tests, ctx->trace_variant);
     if (int rc = timed_end(tl)) return rc;
   }
-  launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters);
-  launch_shade(sl.stream, ctx->scene, in, out, sl.hits, ctx->pix_count, (uint32_t)ctx->iteration,
-               ctx->staging() ? 0u : (uint32_t)ctx->iteration, bounce, last, slot_base_dev, sl.chunk_offsets, sl.stage,
-               ctx->band, sl.counters);
+  launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
+  launch_shade(sl.stream, ctx->scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
+               sl.chunk_offsets, sl.stage, ctx->band, sl.counters, sl.bi);
   sl.cur ^= 1;
   sl.bounces_done = bounce + 1;
   return check_last(ctx, "bounce");
 }
 
-int ptc_trace_end(ptc_ctx* ctx)
+int batch_end(ptc_ctx* ctx)
 {
-  if (!ctx || ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
-  if (int rc = bind_device(ctx)) return rc;
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
   if (ctx->staging()) {
-    // fold this sample in after the previous iteration's fold (running means do not commute)
+    // fold these samples in after the previous iteration's fold (running means do not commute)
     if (ctx->order_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->order_event, 0));
     if (ctx->main_valid) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
-    launch_accumulate(sl.stream, (uint32_t)ctx->iteration, sl.stage, ctx->fb, ctx->pix_count);
+    launch_accumulate(sl.stream, sl.stage, ctx->fb, ctx->pix_count, sl.bi);
     if (int rc = check_last(ctx, "accumulate")) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->order_event, sl.stream));
     ctx->order_valid = true;
@@ -788,6 +845,55 @@ int ptc_trace_end(ptc_ctx* ctx)
   HIP_TRY(ctx, hipEventRecord(sl.done, sl.stream));
   ctx->last_slot = ctx->active_slot;
   ctx->active_slot = -1;
+  return PTC_OK;
+}
+
+// frames per batch ptc_trace may use right now (only the default traversal kernel reads DBatchInfo)
+int batch_limit(const ptc_ctx* ctx) { return ctx->staged && ctx->trace_variant == 3 ? ctx->batch : 1; }
+
+// enqueue the iterations ptc_trace has queued
+int flush_pending(ptc_ctx* ctx)
+{
+  if (ctx->pending.empty()) return PTC_OK;
+  if (int rc = bind_device(ctx)) return rc;
+  std::vector<ptc_ctx::Pending> items;
+  items.swap(ctx->pending);
+  if (int rc = batch_begin(ctx, items.data(), (int)items.size())) return rc;
+  for (int b = 0; b < ctx->max_bounces; ++b)
+    if (int rc = batch_bounce(ctx, b, nullptr)) {
+      ctx->active_slot = -1;
+      return rc;
+    }
+  return batch_end(ctx);
+}
+
+}  // namespace
+
+int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera)
+{
+  if (int rc = frame_ready(ctx)) return rc;
+  if (!camera) return fail(ctx, PTC_ERR_INVALID, "camera is NULL");
+  if (ctx->active_slot >= 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_end missing");
+  if (int rc = flush_pending(ctx)) return rc;
+  ctx->cam = make_camera(*camera, ctx->width, ctx->height);
+  ctx->have_cam = true;
+  const ptc_ctx::Pending one{ctx->cam, (uint32_t)ctx->iteration};
+  return batch_begin(ctx, &one, 1);
+}
+
+int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
+{
+  if (int rc = frame_ready(ctx)) return rc;
+  if (ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (bounce < 0 || bounce >= ctx->max_bounces) return fail(ctx, PTC_ERR_INVALID, "bounce out of range");
+  return batch_bounce(ctx, bounce, slot_base_dev);
+}
+
+int ptc_trace_end(ptc_ctx* ctx)
+{
+  if (!ctx || ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
+  if (int rc = bind_device(ctx)) return rc;
+  if (int rc = batch_end(ctx)) return rc;
   ++ctx->iteration;
   ++ctx->frames;
   ctx->result = ctx->fb.color4;  // path_tracer.cu:476
@@ -797,8 +903,9 @@ int ptc_trace_end(ptc_ctx* ctx)
 int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr)
 {
   if (!ctx || !dev_ptr || bounce < 0 || bounce > (int)kMaxBounces || ctx->slots.empty()) return PTC_ERR_INVALID;
+  if (int rc = flush_pending(ctx)) return rc;
   const auto& sl = ctx->slots[(size_t)(ctx->active_slot >= 0 ? ctx->active_slot : ctx->last_slot)];
-  *dev_ptr = &sl.counters->live[bounce];
+  *dev_ptr = &sl.counters[sl.bi.count - 1u].live[bounce];  // the most recent iteration of the batch
   return PTC_OK;
 }
 
@@ -827,14 +934,18 @@ int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
 {
   if (int rc = frame_ready(ctx)) return rc;
   if (!camera) return fail(ctx, PTC_ERR_INVALID, "camera is NULL");
+  if (ctx->active_slot >= 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_end missing");
   if (ctx->iteration >= ctx->max_iterations) {  // path_tracer.cu:391
     ctx->result = ctx->fb.color4;
     return PTC_OK;
   }
   if (ctx->method == PTC_METHOD_MEGAKERNEL) {
     // one kernel per sample, accumulating in place: frames are serialised on slot 0's stream
-    if (ctx->staging())
+    if (ctx->staging()) {
       if (int rc = sync_frames(ctx)) return rc;
+    } else if (int rc = flush_pending(ctx)) {
+      return rc;
+    }
     auto& sl = ctx->slots[0];
     ctx->cam = make_camera(*camera, ctx->width, ctx->height);
     ctx->have_cam = true;
@@ -847,18 +958,21 @@ int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
       ctx->order_valid = true;
     }
     ctx->last_slot = 0;
+    sl.bi.count = 1u;
     ++ctx->iteration;
     ++ctx->frames;
     ctx->result = ctx->fb.color4;
     return PTC_OK;
   }
-  if (int rc = ptc_trace_begin(ctx, camera)) return rc;
-  for (int b = 0; b < ctx->max_bounces; ++b)
-    if (int rc = ptc_trace_bounce(ctx, b, nullptr)) {
-      ctx->active_slot = -1;
-      return rc;
-    }
-  return ptc_trace_end(ctx);
+  // streaming mode: queue the iteration; a full batch goes to the GPU
+  ctx->cam = make_camera(*camera, ctx->width, ctx->height);
+  ctx->have_cam = true;
+  ctx->pending.push_back(ptc_ctx::Pending{ctx->cam, (uint32_t)ctx->iteration});
+  ++ctx->iteration;
+  ++ctx->frames;
+  ctx->result = ctx->fb.color4;  // path_tracer.cu:476
+  if ((int)ctx->pending.size() >= batch_limit(ctx)) return flush_pending(ctx);
+  return PTC_OK;
 }
 
 int ptc_denoise(ptc_ctx* ctx)
@@ -866,6 +980,7 @@ int ptc_denoise(ptc_ctx* ctx)
   if (int rc = frame_ready(ctx)) return rc;
   if (!ctx->have_cam) return fail(ctx, PTC_ERR_INVALID, "denoise needs a traced frame (it reuses the last camera)");
   if (ctx->pix_count != ctx->width * ctx->height) return fail(ctx, PTC_ERR_INVALID, "denoise needs the full frame in one context");
+  if (int rc = flush_pending(ctx)) return rc;
   // every sample must be folded in before the framebuffers are read (stream order, no host sync)
   if (ctx->order_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_event, 0));
   else if (!ctx->slots.empty() && ctx->slots[(size_t)ctx->last_slot].stream != ctx->stream)
@@ -897,6 +1012,7 @@ int ptc_present_rgba8(ptc_ctx* ctx, void* dst, int dst_is_device, int display_ty
   if (!ctx || !dst) return PTC_ERR_INVALID;
   if (!ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
   if (int rc = bind_device(ctx)) return rc;
+  if (int rc = flush_pending(ctx)) return rc;
   const float4* src = nullptr;
   int mode = 0;
   switch (display_type) {
@@ -921,6 +1037,7 @@ int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device)
   if (!ctx || !dst) return PTC_ERR_INVALID;
   if (!ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
   if (int rc = bind_device(ctx)) return rc;
+  if (int rc = flush_pending(ctx)) return rc;
   const float4* src = nullptr;
   int sel = 0;
   size_t floats = (size_t)ctx->pix_count * 3u;
@@ -956,14 +1073,15 @@ int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
   uint32_t flags = 0;
   const size_t head = offsetof(DeviceCounters, work);  // everything but the fetch cursors
   std::vector<char> buf(sizeof(DeviceCounters));
-  for (size_t f = 0; f < ctx->slots.size(); ++f) {
-    HIP_TRY(ctx, hipMemcpy(buf.data(), ctx->slots[f].counters, head, hipMemcpyDeviceToHost));
-    const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
-    out->rays_total += host.rays_total;
-    flags |= host.flags;
-    if ((int)f == ctx->last_slot)
-      for (int i = 0; i < PTC_MAX_BOUNCES_CAP; ++i) out->last_live[i] = i < ctx->max_bounces ? host.live[i] : 0u;
-  }
+  for (size_t f = 0; f < ctx->slots.size(); ++f)
+    for (int k = 0; k < ctx->batch; ++k) {
+      HIP_TRY(ctx, hipMemcpy(buf.data(), ctx->slots[f].counters + k, head, hipMemcpyDeviceToHost));
+      const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
+      out->rays_total += host.rays_total;
+      flags |= host.flags;
+      if ((int)f == ctx->last_slot && k + 1 == (int)ctx->slots[f].bi.count)
+        for (int i = 0; i < PTC_MAX_BOUNCES_CAP; ++i) out->last_live[i] = i < ctx->max_bounces ? host.live[i] : 0u;
+    }
   HIP_TRY(ctx, hipMemcpy(buf.data(), ctx->misc_counters, head, hipMemcpyDeviceToHost));
   flags |= reinterpret_cast<const DeviceCounters*>(buf.data())->flags;
   out->frames = ctx->frames;
@@ -1008,7 +1126,8 @@ int ptc_reset_profile(ptc_ctx* ctx)
   std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
   const size_t off = offsetof(DeviceCounters, paths), end = offsetof(DeviceCounters, work);
   for (auto& sl : ctx->slots)
-    HIP_TRY(ctx, hipMemset(reinterpret_cast<char*>(sl.counters) + off, 0, end - off));
+    for (int k = 0; k < ctx->batch; ++k)
+      HIP_TRY(ctx, hipMemset(reinterpret_cast<char*>(sl.counters + k) + off, 0, end - off));
   return PTC_OK;
 }
 
@@ -1021,8 +1140,9 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
   std::memset(out, 0, sizeof *out);
   const size_t head = offsetof(DeviceCounters, work);
   std::vector<char> buf(sizeof(DeviceCounters));
-  for (auto& sl : ctx->slots) {
-    HIP_TRY(ctx, hipMemcpy(buf.data(), sl.counters, head, hipMemcpyDeviceToHost));
+  for (auto& sl : ctx->slots)
+    for (int k = 0; k < ctx->batch; ++k) {
+    HIP_TRY(ctx, hipMemcpy(buf.data(), sl.counters + k, head, hipMemcpyDeviceToHost));
     const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
     for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {
       out->paths[b] += host.paths[b];

@@ -183,24 +183,32 @@ int ptc_set_max_iterations(ptc_ctx* ctx, int max_iterations);       /* PathTrace
 int ptc_set_method(ptc_ctx* ctx, int method);                       /* PathTracer::current_gpu_method */
 int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces);             /* static max_bounces = 50, path_tracer.cu:27 */
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* PathTracer::atrous_denoiser */
-/* Closest-hit kernel variant:
- *   3           = like 2 over the tree collapsed to four children per 128-byte node; box decisions only
- *                 conservative, every candidate triangle re-checked against its parent's box with the
- *                 reference's arithmetic (sufficient: see DESIGN.md "nesting")
- *   2 (default) = culled near-first traversal over the wide node layout, persistent wavefronts whose lanes
- *                 fetch the next ray as soon as their own is finished; objects walked as sphere / mesh segments
- *   1           = the same traversal, one wavefront per 64 fixed paths
+/* Closest-hit kernel variant (speed only; all return the same hits, bit for bit -- same box decisions, same
+ * tie rule; 0-2 and 4 exist to cross-check the default on the GPU):
+ *   3 (default) = persistent wavefronts whose lanes fetch the next ray as soon as their own is finished, over the
+ *                 tree collapsed to four children per 128-byte node; box decisions only conservative, the
+ *                 winning triangle re-checked against its parent's box with the reference's arithmetic
+ *                 (sufficient: see DESIGN.md "nesting"); objects walked as sphere / mesh segments; the only
+ *                 variant that traces several iterations per launch ("batch_frames")
+ *   4           = the same scheme over two-child 64-byte records
+ *   2           = persistent wavefronts, exact box decisions inside the loop
+ *   1           = culled near-first traversal, one wavefront per 64 fixed paths
  *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no
- *                 t culling)
- * All return the same hits (same box decisions, same tie rule); 0 and 1 exist to cross-check 2 on the GPU. */
+ *                 t culling) */
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
 /* Tuning knobs (speed only, never results).  Known names:
- *   "traverse_waves"   persistent wavefronts launched per traversal segment (default 4096; before ptc_upload_scene)
- *   "frames_in_flight" consecutive iterations traced concurrently on separate streams, folded into the
- *                      framebuffer in iteration order (default 16; 1 = strictly serial on the context's
- *                      stream; set before ptc_resize).  ROCm runs streams on GPU_MAX_HW_QUEUES hardware
- *                      queues (default 4): export GPU_MAX_HW_QUEUES=16 to let them all overlap
+ *   "frames_in_flight" consecutive iterations in flight at once, folded into the framebuffer in iteration order
+ *                      (default: 64, fewer when their path state would exceed 24 GiB; 1 = strictly serial on
+ *                      the context's stream; 1..256; set before ptc_resize)
+ *   "batch_frames"     iterations traced by the same launches (default 8; 1..16; before ptc_resize).  ptc_trace
+ *                      queues an iteration and enqueues the batch when it is full or when any other call
+ *                      looks at the context; frames_in_flight / batch_frames batches run on separate streams.
+ *                      The library asks the HIP runtime for 24 hardware queues (GPU_MAX_HW_QUEUES, default 4:
+ *                      streams on one queue serialise) when it is loaded before the runtime starts; an
+ *                      application that initialises HIP first should export GPU_MAX_HW_QUEUES=24 itself
+ *   "traverse_waves"   persistent wavefronts per traversal launch (default 2048; before ptc_upload_scene)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
+ *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 7 = 7/8)
  *   "leaf_batch"       lanes that must hold an untested leaf before the triangle tests run (default 1)
  *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);

@@ -59,6 +59,22 @@ def test_every_schedule_matches_reference_order_and_oracle(pkg, orc, small_scene
             assert same(got, base), (variant, fif)
 
 
+@pytest.mark.parametrize("name", ["spheres", "instances", "heightfield"])
+def test_batched_iterations_match_serial(pkg, small_scenes, name):
+    """Several iterations traced by the same launches (batch_frames; DBatchInfo): full batches, a partial last
+    batch (7 = 3+3+1, 4+3), one slot or several, few wavefronts (no static share) or many."""
+    scene, w, h = small_scenes[name]
+    flat = scene.build_scene()
+    base = frames(pkg, scene, flat, w, h, 7, 8, variant=0, fif=1)
+    for fif, batch, waves in ((3, 3, 6144), (8, 4, 6144), (8, 8, 256), (6, 2, 24), (4, 4, 8)):
+        got = frames(pkg, scene, flat, w, h, 7, 8, fif=fif,
+                     params=(("batch_frames", batch), ("traverse_waves", waves)))
+        assert same(got, base), (fif, batch, waves)
+    # every ray through k_slow_rays with batch-global slots
+    got = frames(pkg, scene, flat, w, h, 7, 8, fif=4, params=(("batch_frames", 4), ("debug_force_slow", 2)))
+    assert same(got, base)
+
+
 def test_degenerate_ray_fallback_kernel(pkg, small_scenes):
     """k_slow_rays (rays whose direction has a zero / subnormal component) forced for every ray"""
     scene, w, h = small_scenes["instances"]
