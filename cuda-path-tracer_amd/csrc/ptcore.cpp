@@ -123,7 +123,7 @@ struct ptc_ctx {
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
   uint32_t traverse_waves = 2048;
   uint32_t refill_lanes = 20;
-  uint32_t static_eighths = 7;
+  uint32_t static_eighths = 3;
   uint32_t leaf_batch = 1;  // measured: batching the triangle tests (8..48 lanes) delays the hit that prunes the rest of the walk and loses 5-30 %
   int force_slow = 0;
 

@@ -9,11 +9,13 @@ tag=sys.argv[1]
 for F,B,waves in [tuple(int(x) for x in a.split(',')) if ',' in a else (16,2,int(a)) for a in sys.argv[2:]]:
   with pkg.PathTracer(max_bounces=8) as pt:
     pt.set_param('frames_in_flight', F); pt.set_param('batch_frames', B); pt.set_param('traverse_waves', waves)
+    for kv in filter(None, os.environ.get('EXTRA','').split(',')):
+      k,v=kv.split('='); pt.set_param(k,int(v))
     pt.create_buffers((W,H), flat); pt.max_iterations=1<<30
     if os.environ.get('SHARE'): pt.set_interleave(0, int(os.environ['SHARE']), 8)
-    for i in range(16): pt.path_trace(sc.camera)
+    for i in range(64): pt.path_trace(sc.camera)
     pt.synchronize(); r0=pt.stats()['rays_total']
-    K=64
+    K=int(os.environ.get('K','256'))
     t=time.time()
     for i in range(K): pt.path_trace(sc.camera)
     pt.synchronize(); dt=(time.time()-t)
