@@ -1992,15 +1992,22 @@ __global__ __launch_bounds__(256) void k_denoise_positions(DCamera cam, uint32_t
   pos[index] = make_float4(p.x, p.y, p.z, 0.0f);
 }
 
-__global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count, const float4* color, const float4* nd,
-                                                 const float4* pos, float4* out, int step_width, DDenoise prm)
+// Arithmetic of the pass: the three edge-stopping weights min(exp(-d/phi), 1) of a tap (cu:63-77) multiply to
+// exp(-(dc/c_phi + dn/(step^2 n_phi) + dp/p_phi)) -- every d is a sum of squares, so no factor exceeds 1 and the
+// clamps are inert.  The kernel evaluates that single exponential with v_exp_f32 on a base-2 argument whose
+// three reciprocal scale factors are computed once per pass (the reference: three divisions and three expf per
+// tap, 75 of each per pixel per pass, which made this kernel VALU-bound).  This stage is outside the random-number
+// feedback loop and is compared with the oracle under a tolerance (1e-5 absolute on the radiance,
+// tests/test_gpu_parity.py), not bit for bit; contraction into FMAs is allowed here for the same reason.
+// kInterior: every tap of the tile is inside the image (no clamp, no off-by-one column / row): the common case,
+// decided per tile so that the wavefront does not branch per tap.
+template <bool kInterior>
+__device__ __forceinline__ void denoise_pixel(const DCamera& cam, const uint32_t pix_count, const float4* color,
+                                              const float4* nd, const float4* pos, float4* out, const int step_width,
+                                              const DDenoise& prm, const int x, const int y)
 {
-  // 16x16 pixel tiles: neighbouring threads share most of their (dilated) taps in L1/L2
+#pragma clang fp contract(fast)
   const uint32_t W = cam.width, H = cam.height;
-  const uint32_t tiles_x = (W + 15u) / 16u;
-  const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x = (int)(tx * 16u + (threadIdx.x & 15u)), y = (int)(ty * 16u + (threadIdx.x >> 4));
-  if (x >= (int)W || y >= (int)H) return;
   const uint32_t index = (uint32_t)x + (uint32_t)y * W;
   const float kernel[3] = {3.f / 8.f, 1.f / 4.f, 1.f / 16.f};
   const f3 cval = xyz(color[index]);
@@ -2009,42 +2016,54 @@ __global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count
   f3 sum = mk3(0.f, 0.f, 0.f);
   float cum_w = 0.0f;
   const float step2 = (float)(step_width * step_width);
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float kc = -kLog2e / prm.c_phi, kn = -kLog2e / (step2 * prm.n_phi), kp = -kLog2e / prm.p_phi;
+#pragma unroll 1
   for (int dy = -2; dy <= 2; ++dy) {
+    int v = y + dy * step_width;
+    if (!kInterior) v = v < 0 ? 0 : (v > (int)H ? (int)H : v);
+#pragma unroll
     for (int dx = -2; dx <= 2; ++dx) {
       int u = x + dx * step_width;
-      u = u < 0 ? 0 : (u > (int)W ? (int)W : u);
-      int v = y + dy * step_width;
-      v = v < 0 ? 0 : (v > (int)H ? (int)H : v);
+      if (!kInterior) u = u < 0 ? 0 : (u > (int)W ? (int)W : u);
       uint32_t ti = (uint32_t)u + (uint32_t)v * W;
-      if (ti >= pix_count) ti = pix_count - 1u;
+      if (!kInterior && ti >= pix_count) ti = pix_count - 1u;
       const f3 ctemp = xyz(color[ti]);
-      f3 t = cval - ctemp;
-      float dist2 = dot(t, t);
-      const float c_w = sel_min(expf(-dist2 / prm.c_phi), 1.0f);
       const float4 ndt = nd[ti];
-      t = nval - xyz(ndt);
-      dist2 = sel_max(dot(t, t) / step2, 0.0f);
-      const float n_w = sel_min(expf(-dist2 / prm.n_phi), 1.0f);
       f3 ptmp;
-      if (u == (int)W || v == (int)H) {  // the reference's off-by-one taps keep their own view ray
+      if (!kInterior && (u == (int)W || v == (int)H)) {  // the reference's off-by-one taps keep their own view ray
         f3 to, td;
         generate_ray(cam, (float)u + 0.5f, (float)v + 0.5f, to, td);
         ptmp = to + td * ndt.w;
       } else {
         ptmp = xyz(pos[ti]);
       }
-      t = pval - ptmp;
-      dist2 = dot(t, t);
-      const float p_w = sel_min(expf(-dist2 / prm.p_phi), 1.0f);
-      const float weight = c_w * n_w * p_w;
+      const f3 tc = cval - ctemp, tn = nval - xyz(ndt), tp = pval - ptmp;
+      const float arg = dot(tc, tc) * kc + dot(tn, tn) * kn + dot(tp, tp) * kp;
+      const float weight = __builtin_amdgcn_exp2f(arg);
       const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-      const float k = kernel[adx < ady ? adx : ady];
-      sum = sum + (ctemp * weight) * k;
-      cum_w += weight * k;
+      const float wk = weight * kernel[adx < ady ? adx : ady];
+      sum = sum + ctemp * wk;
+      cum_w += wk;
     }
   }
-  const f3 o = sum / cum_w;
-  out[index] = make_float4(o.x, o.y, o.z, 0.0f);
+  const float inv_w = 1.0f / cum_w;
+  out[index] = make_float4(sum.x * inv_w, sum.y * inv_w, sum.z * inv_w, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count, const float4* color, const float4* nd,
+                                                 const float4* pos, float4* out, int step_width, DDenoise prm)
+{
+  // 16x16 pixel tiles: neighbouring threads share most of their (dilated) taps in L1/L2
+  const int W = (int)cam.width, H = (int)cam.height;
+  const uint32_t tiles_x = ((uint32_t)W + 15u) / 16u;
+  const int x0 = (int)(blockIdx.x % tiles_x) * 16, y0 = (int)(blockIdx.x / tiles_x) * 16;
+  const int x = x0 + (int)(threadIdx.x & 15u), y = y0 + (int)(threadIdx.x >> 4);
+  if (x >= W || y >= H) return;
+  const int reach = 2 * step_width;
+  const bool interior = x0 - reach >= 0 && y0 - reach >= 0 && x0 + 15 + reach < W && y0 + 15 + reach < H;
+  if (interior) denoise_pixel<true>(cam, pix_count, color, nd, pos, out, step_width, prm, x, y);
+  else denoise_pixel<false>(cam, pix_count, color, nd, pos, out, step_width, prm, x, y);
 }
 
 __global__ void k_selftest(const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt, float* out_sin,

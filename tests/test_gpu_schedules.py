@@ -129,6 +129,81 @@ def test_frames_in_flight_are_folded_in_order(pkg, small_scenes):
     assert np.array_equal(mid, five["color"])
 
 
+def test_queued_iterations_are_flushed_by_every_consumer(pkg, small_scenes):
+    """ptc_trace only queues an iteration until its batch is full: everything else that looks at the context
+    (download, stats, denoise, the stepwise calls, the megakernel, restart, a changed bounce cap) must see all
+    queued iterations, in order.  Reference for each step: strictly serial contexts."""
+    scene, w, h = small_scenes["instances"]
+    flat = scene.build_scene()
+    cam = scene.camera
+
+    def serial(n, mb=6, method=None):
+        with pkg.PathTracer(max_bounces=mb) as pt:
+            pt.set_param("frames_in_flight", 1)
+            pt.create_buffers((w, h), flat)
+            pt.max_iterations = 1 << 20
+            if method is not None:
+                pt.current_gpu_method = method
+            for _ in range(n):
+                pt.path_trace(cam)
+            return pt.download("color"), pt.stats()
+
+    with pkg.PathTracer(max_bounces=6) as pt:
+        pt.set_param("frames_in_flight", 8)
+        pt.set_param("batch_frames", 4)
+        pt.create_buffers((w, h), flat)
+        pt.max_iterations = 1 << 20
+        for _ in range(3):                       # 3 of 4 queued
+            pt.path_trace(cam)
+        assert pt.iteration() == 3
+        c3, st3 = serial(3)
+        assert np.array_equal(pt.download("color"), c3)            # download flushes the partial batch
+        for _ in range(2):                       # 2 queued
+            pt.path_trace(cam)
+        st = pt.stats()                           # stats flushes
+        c5, st5 = serial(5)
+        assert st["rays_total"] == st5["rays_total"] and st["last_live"] == st5["last_live"] and st["frames"] == 5
+        pt.path_trace(cam)                        # 1 queued, then a stepwise frame
+        pt.trace_begin(cam)
+        for b in range(6):
+            pt.trace_bounce(b)
+        pt.trace_end()
+        assert pt.iteration() == 7
+        c7, _ = serial(7)
+        assert np.array_equal(pt.download("color"), c7)
+        pt.path_trace(cam)                        # 1 queued, then the frame restarts
+        pt.restart()
+        for _ in range(6):                       # 4 + 2
+            pt.path_trace(cam)
+        c6, _ = serial(6)
+        assert np.array_equal(pt.download("color"), c6)
+        # denoise sees the queued iterations
+        pt.restart()
+        for _ in range(3):
+            pt.path_trace(cam)
+        pt.denoise()
+        den = pt.download("final")
+    with pkg.PathTracer(max_bounces=6) as ref:
+        ref.set_param("frames_in_flight", 1)
+        ref.create_buffers((w, h), flat)
+        ref.max_iterations = 1 << 20
+        for _ in range(3):
+            ref.path_trace(cam)
+        ref.denoise()
+        assert np.array_equal(ref.download("final"), den)
+    # max_iterations: queued iterations count, further calls are no-ops (path_tracer.cu:391)
+    with pkg.PathTracer(max_bounces=6) as pt:
+        pt.set_param("frames_in_flight", 8)
+        pt.set_param("batch_frames", 4)
+        pt.create_buffers((w, h), flat)
+        pt.max_iterations = 6
+        for _ in range(9):
+            pt.path_trace(cam)
+        assert pt.iteration() == 6
+        c6b, _ = serial(6)
+        assert np.array_equal(pt.download("color"), c6b)
+
+
 @pytest.fixture(scope="module")
 def big(pkg):
     scene = pkg.scenes.heightfield_scene((1920, 1080))

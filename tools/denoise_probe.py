@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.')
+import sys, time; sys.path.insert(0,'/root/repo')
 import numpy as np
 import __graft_entry__ as g
 pkg=g.load_package()
