@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
             near_z = inv.z < 0.0f ? 80u : 32u;
             best_t = t_in;
             best_k = -1;
-            limit = scale * best_t;
+            limit = scale * best_t * 1.001f;
             cur = sc.bvh4_root;
             pend = kNoChild;
             sp = 0;
@@ -1274,15 +1274,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       const float fxa[4] = {fx.x, fx.y, fx.z, fx.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        // an unused child slot holds the empty box (+inf, -inf): its near value is +inf, it is never taken
-        const float tn = fmaxf(fmaxf(__builtin_fmaf(nxa[c], inv.x, oin.x), __builtin_fmaf(nya[c], inv.y, oin.y)),
-                               __builtin_fmaf(nza[c], inv.z, oin.z));
-        const float tf = fminf(fminf(__builtin_fmaf(fxa[c], inv.x, oif.x), __builtin_fmaf(fya[c], inv.y, oif.y)),
-                               __builtin_fmaf(fza[c], inv.z, oif.z));
-        const bool miss = (tf - tn) < -1e-4f * (fabsf(tn) + fabsf(tf));
-        const bool go = !(miss | box_culled(tn, tf, limit));
+        // tn is a lower bound of the true entry distance and tf an upper bound of the true exit distance (the
+        // tolerance is inside oin / oif), so the child can be skipped when the interval [max(tn, 0), min(tf,
+        // limit)] is empty: box missed, box behind the origin (every t in it < 0 < t_min), or box beyond the
+        // closest hit so far (limit carries a 0.1 % margin; ties at equal t start no farther than the hit).
+        // An unused child slot holds the empty box (+inf, -inf): never taken.
+        const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nxa[c], inv.x, oin.x), __builtin_fmaf(nya[c], inv.y, oin.y)),
+                                     __builtin_fmaf(nza[c], inv.z, oin.z)), 0.0f);
+        const float tf = fminf(fminf(fminf(__builtin_fmaf(fxa[c], inv.x, oif.x), __builtin_fmaf(fya[c], inv.y, oif.y)),
+                                     __builtin_fmaf(fza[c], inv.z, oif.z)), limit);
         if (kCount && ref[c] != kNoChild) { ++tally.boxes; ++ray_boxes; }
-        key[c] = go ? tn : __builtin_inff();
+        key[c] = tn <= tf ? tn : __builtin_inff();
       }
       // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
       auto cx = [&](int a, int b) {
@@ -1299,9 +1301,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       cx(0, 2);
       cx(1, 3);
       cx(1, 2);
-      if (key[3] < __builtin_inff()) push(ref[3]);
-      if (key[2] < __builtin_inff()) push(ref[2]);
-      if (key[1] < __builtin_inff()) push(ref[1]);
+      // the others go on the stack, farthest first
+      if (__builtin_expect(sp + 3 <= kLds4, 1)) {
+        // room for all three in LDS: write unconditionally, advance only past the ones that count (a slot that
+        // does not count is overwritten by the next write or stays above the top)
+        stack[sp * kWave] = ref[3];
+        sp += key[3] < __builtin_inff() ? 1 : 0;
+        stack[sp * kWave] = ref[2];
+        sp += key[2] < __builtin_inff() ? 1 : 0;
+        stack[sp * kWave] = ref[1];
+        sp += key[1] < __builtin_inff() ? 1 : 0;
+      } else {
+        if (key[3] < __builtin_inff()) push(ref[3]);
+        if (key[2] < __builtin_inff()) push(ref[2]);
+        if (key[1] < __builtin_inff()) push(ref[1]);
+      }
       cur = key[0] < __builtin_inff() ? ref[0] : pop();
     }
     const uint64_t pend_mask = __ballot(active && pend != kNoChild);
@@ -1328,7 +1342,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
               if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
                 best_t = t;
                 best_k = (int)k;
-                limit = scale * t;
+                limit = scale * t * 1.001f;
               }
             }
           }

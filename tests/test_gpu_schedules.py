@@ -213,17 +213,31 @@ def big(pkg):
 
 
 def test_benchmark_size_against_reference_order(pkg, big):
-    """1920x1080, 1,000,000 triangles, 8 bounces, 2 iterations: default schedule == reference-order kernel."""
+    """1920x1080, 1,000,000 triangles, 8 bounces, 10 iterations (a full batch of 8 and a partial one under the
+    default schedule): default schedule == reference-order kernel, strictly serial."""
     scene, flat, depth = big
     assert len(flat.indices) // 3 == 1_000_000 and len(flat.bvh) == 1_999_999
-    base = frames(pkg, scene, flat, 1920, 1080, 2, 8, variant=0, fif=1)
-    got = frames(pkg, scene, flat, 1920, 1080, 2, 8)
+    base = frames(pkg, scene, flat, 1920, 1080, 10, 8, variant=0, fif=1)
+    got = frames(pkg, scene, flat, 1920, 1080, 10, 8)
     assert same(got, base)
     live = got["stats"]["last_live"]
     assert live[0] == 1920 * 1080 and all(a >= b for a, b in zip(live, live[1:]))
     assert np.isfinite(got["color"]).all() and 0.0 <= got["color"].min() and got["color"].max() <= 1.0 + 1e-6
     # a miss keeps the raygen depth of 1e6 (ray_gen.cu:27); hits are closer
     assert np.isclose(got["depth"].max(), 1e6) and got["depth"].min() > 0.5
+
+
+def test_config2_size_against_reference_order(pkg):
+    """Config 2: 1280x720, Cornell box + two instances of the 69,984-triangle mesh (one traversal
+    launch per instance and bounce, hits carried between the object segments), 8 bounces, 9 iterations."""
+    scene = pkg.scenes.cornell_bunny((1280, 720))
+    flat = scene.build_scene()
+    assert len(flat.indices) // 3 == 69_984
+    base = frames(pkg, scene, flat, 1280, 720, 9, 8, variant=0, fif=1)
+    got = frames(pkg, scene, flat, 1280, 720, 9, 8)
+    assert same(got, base)
+    got4 = frames(pkg, scene, flat, 1280, 720, 9, 8, variant=4, fif=4)
+    assert same(got4, base)
 
 
 def test_benchmark_size_rays_against_oracle(pkg, orc, big):
