@@ -1060,7 +1060,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
                                                      DBatchInfo bi)
 {
   __shared__ uint32_t s_stack[kLds4 * kWave];
-  uint32_t* stack = s_stack + threadIdx.x;
+  // explicitly an LDS pointer: as a generic pointer the pop below compiles to a flat load
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  lds_u32* stack = (lds_u32*)s_stack + threadIdx.x;
   const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
   // `slot` below is batch-global (frame * bi.stride + slot in the frame); flags, the slow-ray list and the
   // test tallies of the whole batch go to frame 0's counters
