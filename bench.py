@@ -46,15 +46,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 8 streams x the batch size")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = streams x the batch size")
     ap.add_argument("--batch-frames", type=int, default=0,
-                    help="frames traced per launch; 0 = min(8, steps / 8) so that the timed steps fill 8 streams")
+                    help="frames traced per launch; 0 = up to 32, chosen so that the timed steps split evenly over the streams")
+    ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 on one GPU, 4 per rank on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
@@ -101,15 +102,23 @@ def main():
 
     pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
     # Schedule: `batch` consecutive frames share every launch (the latency tail of a bounce -- a few long rays --
-    # is paid once per batch) and 8 batches are in flight on 8 streams (the hardware overlaps about four kernels;
-    # the rest keep its queues fed).  Results do not depend on it (tests/test_gpu_schedules.py).
-    batch = args.batch_frames or max(1, min(8, args.steps // 8))
+    # and the drain of the persistent wavefronts are paid once per batch) and `streams` batches are in flight so
+    # that the small kernels and the tail of one overlap the bulk of another.  A rank that owns 1/N of the rows
+    # has 1/N of the rays per launch and keeps 4 batches in flight.  Results do not depend on any of it
+    # (tests/test_gpu_schedules.py).
+    streams = args.streams or (2 if world == 1 else 4)
+    if args.batch_frames:
+        batch = args.batch_frames
+    else:
+        rounds = max(1, -(-args.steps // (streams * 32)))
+        batch = max(1, min(32, -(-args.steps // (streams * rounds))))
     args.batch_frames = batch
-    args.frames_in_flight = args.frames_in_flight or 8 * batch
+    args.frames_in_flight = args.frames_in_flight or streams * batch
     pt.set_param("frames_in_flight", args.frames_in_flight)
     pt.set_param("batch_frames", batch)
-    # persistent traversal wavefronts per launch: 8 per CU; with ~4 launches executing at once the GPU is full
-    pt.set_param("traverse_waves", 2048)
+    # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU (a second launch's
+    # wavefronts move in as the first one's drain); half of that for the smaller launches of a multi-GPU rank
+    pt.set_param("traverse_waves", 5120 if world == 1 else 2560)
     pt.create_buffers((W, H), flat)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     if world > 1:

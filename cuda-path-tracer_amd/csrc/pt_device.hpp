@@ -152,6 +152,7 @@ struct DeviceCounters {
   uint32_t max_box_tests[kMaxBounces];        // longest single traversal (box tests of one ray), instrumented runs
   uint32_t max_ray_cycles[kMaxBounces];       // longest single traversal in shader clocks (s_memtime), instrumented runs
   uint32_t max_wave_cycles[kMaxBounces];      // longest-lived persistent wavefront, instrumented runs
+  unsigned long long slow_rays[kMaxBounces];  // rays redone by k_slow_rays
   // ray-fetch cursors of the persistent traversal launches, one per image region, each on its own 128-byte
   // line (cursors sharing a line serialise in L2: measured ~30 atomics/us for the whole line)
   uint32_t work[kWorkSlots][8][32];
@@ -162,7 +163,7 @@ struct DeviceCounters {
 // one bounce cover all frames of the batch (blockIdx.y = frame; the persistent traversal kernel feeds its lanes
 // from all of them).  One launch then carries count times the rays, so the latency tail of a bounce (a few
 // long rays) is paid once per batch instead of once per frame.
-constexpr int kMaxBatch = 16;
+constexpr int kMaxBatch = 32;
 struct DBatchInfo {
   uint32_t stride, chunk_stride, count, pad;
   uint32_t iteration[kMaxBatch];
@@ -193,7 +194,7 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
                      uint32_t* slow_list, const DBatchInfo& bi);
 // rays with a degenerate direction that the persistent kernels set aside: reference-order traversal
 void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                      const uint32_t* slow_list, DeviceCounters* counters);
+                      const uint32_t* slow_list, DeviceCounters* counters, int bounce);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters, const DBatchInfo& bi);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

@@ -1637,9 +1637,12 @@ void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 
 // Rays a persistent traversal launch set aside (degenerate direction): the reference's own traversal order
 // with its exact box tests (ray_mesh).  One workgroup; the list is almost always empty.
+// Capped at 32 VGPRs (the rest lives in scratch): the launch is almost always empty, but it sits in the
+// dependency chain of every bounce, and with 68 registers its one wavefront could not be placed while another
+// stream's persistent traversal wavefronts (5 x 96 registers per SIMD) held the chip -- it waited ~1 ms per bounce.
 template <bool kFirst>
 __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_index, DPaths paths, DHits hits,
-                                                     const uint32_t* slow_list, DeviceCounters* counters)
+                                                     const uint32_t* slow_list, DeviceCounters* counters, int bounce)
 {
   __shared__ uint32_t s_stack[kStackDepth * kWave];
   const uint32_t count = counters->slow_count;
@@ -1659,7 +1662,9 @@ __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_ind
     rec.mat = 0u;
     rec.side = 0u;
     Tally unused;
-    if (ray_mesh<false>(ray, sc, obj, rec, s_stack + threadIdx.x, flags, unused)) {
+    // the object's world box first (path_tracer.cu:84): the persistent kernels test it only for their winners
+    if (ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax)) &&
+        ray_mesh<false>(ray, sc, obj, rec, s_stack + threadIdx.x, flags, unused)) {
       hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
       hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(mat | (rec.side << 31)));
     } else if (kFirst) {
@@ -1668,7 +1673,10 @@ __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_ind
   }
   if (flags) atomicOr(&counters->flags, flags);
   __syncthreads();
-  if (threadIdx.x == 0u) counters->slow_count = 0u;
+  if (threadIdx.x == 0u) {
+    counters->slow_rays[bounce] += count;
+    counters->slow_count = 0u;
+  }
 }
 
 // Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test,
@@ -2139,10 +2147,10 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
     hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
 }
 void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                      const uint32_t* slow_list, DeviceCounters* counters)
+                      const uint32_t* slow_list, DeviceCounters* counters, int bounce)
 {
-  if (first) hipLaunchKernelGGL((k_slow_rays<true>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters);
-  else hipLaunchKernelGGL((k_slow_rays<false>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters);
+  if (first) hipLaunchKernelGGL((k_slow_rays<true>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters, bounce);
+  else hipLaunchKernelGGL((k_slow_rays<false>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters, bounce);
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,

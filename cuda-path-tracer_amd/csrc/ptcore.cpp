@@ -69,6 +69,8 @@ struct ptc_ctx {
     uint32_t* chunk_counts = nullptr;
     uint32_t* chunk_offsets = nullptr;
     uint32_t* slow_list = nullptr;  // slots of rays set aside for k_slow_rays
+    uint2* spill = nullptr;         // traversal stack overflow area of this slot's launches (DScene::spill)
+    size_t spill_elems = 0;
     DFrame stage{};
     DeviceCounters* counters = nullptr;  // one per frame of the batch
     hipEvent_t done = nullptr;  // after this slot's last accumulate
@@ -82,7 +84,7 @@ struct ptc_ctx {
   bool frames_auto = true;  // not set by the caller: ptc_resize caps it so that the in-flight state stays under kAutoFrameBytes
   // Batches: up to `batch` consecutive iterations share the launches of a slot (DBatchInfo).  ptc_trace only
   // queues the iteration; the batch is enqueued when it is full or when anything else looks at the context.
-  int batch_frames = 8;   // requested (ptc_set_param, before ptc_resize)
+  int batch_frames = 32;  // requested (ptc_set_param, before ptc_resize)
   int batch = 1;          // allocated per slot
   bool staged = false;    // samples go through staging buffers and k_accumulate
   struct Pending {
@@ -121,7 +123,7 @@ struct ptc_ctx {
     uint32_t begin, end;  // object range (mesh: one object)
   };
   std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
-  uint32_t traverse_waves = 2048;
+  uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
   uint32_t leaf_batch = 1;  // measured: batching the triangle tests (8..48 lanes) delays the hit that prunes the rest of the walk and loses 5-30 %
@@ -287,6 +289,7 @@ void free_slots(ptc_ctx* ctx)
   for (auto& sl : ctx->slots) {
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
     if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.spill) (void)hipFree(sl.spill);
   }
   ctx->slots.clear();
   ctx->pending.clear();
@@ -481,10 +484,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     const uint32_t need2 = depth + 2u > 16u ? depth + 2u - 16u : 0u;
     const uint32_t need4 = 3u * w4.depth + 2u > 24u ? 3u * w4.depth + 2u - 24u : 0u;
     const uint32_t need = std::max(need2, need4);
-    if (need > 0u) {
-      d.spill_cap = need;
-      if (int rc = dev_alloc(ctx, ctx->scene_allocs, &d.spill, (size_t)d.spill_cap * d.spill_stride)) return rc;
-    }
+    d.spill_cap = need;  // the areas themselves belong to the frame slots (batch_begin)
   }
   ctx->bvh4_nodes = w4.node_count;
   ctx->bvh4_depth = w4.depth;
@@ -681,7 +681,7 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (!ctx || !name) return PTC_ERR_INVALID;
   if (int rc = flush_pending(ctx)) return rc;
   if (std::strcmp(name, "batch_frames") == 0) {
-    if (value < 1 || value > kMaxBatch) return fail(ctx, PTC_ERR_INVALID, "batch_frames must be in [1,16]");
+    if (value < 1 || value > kMaxBatch) return fail(ctx, PTC_ERR_INVALID, "batch_frames must be in [1,32]");
     if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set batch_frames before ptc_resize");
     ctx->batch_frames = value;
     return PTC_OK;
@@ -752,6 +752,16 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   // in: with staging that is only the accumulate at the end of the batch (so tracing overlaps the denoise of
   // the previous frame); without staging the shade kernels write the framebuffers directly.
   if (ctx->main_valid && !ctx->staging()) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->main_event, 0));
+  // launches of different slots run at the same time: each slot has its own stack overflow area
+  const size_t spill_need = (size_t)ctx->scene.spill_cap * ctx->scene.spill_stride;
+  if (spill_need > sl.spill_elems) {
+    HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+    if (sl.spill) HIP_TRY(ctx, hipFree(sl.spill));
+    sl.spill = nullptr;
+    sl.spill_elems = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&sl.spill), spill_need * sizeof(uint2)));
+    sl.spill_elems = spill_need;
+  }
   sl.cur = 0;
   sl.work_slot = 0;
   sl.bounces_done = 0;
@@ -773,6 +783,8 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
   const bool last = bounce == ctx->max_bounces - 1;
   DPaths in = sl.paths[sl.cur], out = sl.paths[sl.cur ^ 1];
+  DScene scene = ctx->scene;
+  scene.spill = sl.spill;
   // HIP events around each launch of the dominant (closest-hit) kernel, on the stream it runs on
   auto timed_begin = [&](ptc_ctx::TimedLaunch& tl) -> int {
     if (!ctx->time_trace) return PTC_OK;
@@ -806,24 +818,24 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         }
         ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
         if (int rc = timed_begin(tl)) return rc;
-        launch_traverse(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
+        launch_traverse(sl.stream, scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
                         ctx->count_tests, ctx->traverse_waves, ctx->trace_variant, sl.slow_list, sl.bi);
         if (int rc = timed_end(tl)) return rc;
-        if (ctx->trace_variant >= 3) launch_slow_rays(sl.stream, ctx->scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters);
+        if (ctx->trace_variant >= 3) launch_slow_rays(sl.stream, scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters, bounce);
       } else {
-        launch_spheres(sl.stream, ctx->scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
+        launch_spheres(sl.stream, scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
                        sl.chunk_counts, sl.counters, sl.bi);
       }
     }
   } else {
     ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
     if (int rc = timed_begin(tl)) return rc;
-    launch_trace(sl.stream, ctx->scene, in, sl.hits, ctx->pix_count, bounce, sl.chunk_counts, sl.counters,
+    launch_trace(sl.stream, scene, in, sl.hits, ctx->pix_count, bounce, sl.chunk_counts, sl.counters,
                  ctx->count_tests, ctx->trace_variant);
     if (int rc = timed_end(tl)) return rc;
   }
   launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
-  launch_shade(sl.stream, ctx->scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
+  launch_shade(sl.stream, scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
                sl.chunk_offsets, sl.stage, ctx->band, sl.counters, sl.bi);
   sl.cur ^= 1;
   sl.bounces_done = bounce + 1;
@@ -1151,6 +1163,7 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
       out->max_box_tests[b] = std::max(out->max_box_tests[b], host.max_box_tests[b]);
       out->max_ray_cycles[b] = std::max(out->max_ray_cycles[b], host.max_ray_cycles[b]);
       out->max_wave_cycles[b] = std::max(out->max_wave_cycles[b], host.max_wave_cycles[b]);
+      out->slow_rays[b] += host.slow_rays[b];
     }
   }
   for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {

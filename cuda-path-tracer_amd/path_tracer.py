@@ -211,7 +211,8 @@ class PathTracer:
                 "trace_launches": [int(x) for x in p.trace_launches[:n]],
                 "max_box_tests": [int(x) for x in p.max_box_tests[:n]],
                 "max_ray_cycles": [int(x) for x in p.max_ray_cycles[:n]],
-                "max_wave_cycles": [int(x) for x in p.max_wave_cycles[:n]]}
+                "max_wave_cycles": [int(x) for x in p.max_wave_cycles[:n]],
+                "slow_rays": [int(x) for x in p.slow_rays[:n]]}
 
     def intersect_rays(self, rays):
         """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""

@@ -145,6 +145,7 @@ typedef struct ptc_profile {
   uint32_t max_box_tests[PTC_MAX_BOUNCES_CAP]; /* longest single traversal seen (counting runs) */
   uint32_t max_ray_cycles[PTC_MAX_BOUNCES_CAP];  /* ... in shader clocks, and the longest-lived wavefront */
   uint32_t max_wave_cycles[PTC_MAX_BOUNCES_CAP];
+  uint64_t slow_rays[PTC_MAX_BOUNCES_CAP];   /* rays redone by the reference-order fallback kernel (always counted) */
 } ptc_profile;
 
 typedef struct ptc_ctx ptc_ctx;
@@ -200,13 +201,14 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "frames_in_flight" consecutive iterations in flight at once, folded into the framebuffer in iteration order
  *                      (default: 64, fewer when their path state would exceed 24 GiB; 1 = strictly serial on
  *                      the context's stream; 1..256; set before ptc_resize)
- *   "batch_frames"     iterations traced by the same launches (default 8; 1..16; before ptc_resize).  ptc_trace
+ *   "batch_frames"     iterations traced by the same launches (default 32; 1..32; before ptc_resize).  ptc_trace
  *                      queues an iteration and enqueues the batch when it is full or when any other call
  *                      looks at the context; frames_in_flight / batch_frames batches run on separate streams.
  *                      The library asks the HIP runtime for 24 hardware queues (GPU_MAX_HW_QUEUES, default 4:
  *                      streams on one queue serialise) when it is loaded before the runtime starts; an
  *                      application that initialises HIP first should export GPU_MAX_HW_QUEUES=24 itself
- *   "traverse_waves"   persistent wavefronts per traversal launch (default 2048; before ptc_upload_scene)
+ *   "traverse_waves"   persistent wavefronts per traversal launch (default 5120 = the number that is resident
+ *                      at 5 per SIMD; before ptc_upload_scene)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 7 = 7/8)
  *   "leaf_batch"       lanes that must hold an untested leaf before the triangle tests run (default 1)

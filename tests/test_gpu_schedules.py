@@ -220,6 +220,10 @@ def test_benchmark_size_against_reference_order(pkg, big):
     base = frames(pkg, scene, flat, 1920, 1080, 10, 8, variant=0, fif=1)
     got = frames(pkg, scene, flat, 1920, 1080, 10, 8)
     assert same(got, base)
+    # two-wide persistent kernel, ten single-frame launches in flight on ten streams: its 16-entry LDS stack
+    # overflows into the per-slot global area on this 25-level tree, concurrently in every launch
+    got4 = frames(pkg, scene, flat, 1920, 1080, 10, 8, variant=4, fif=10, params=(("batch_frames", 1),))
+    assert same(got4, base)
     live = got["stats"]["last_live"]
     assert live[0] == 1920 * 1080 and all(a >= b for a, b in zip(live, live[1:]))
     assert np.isfinite(got["color"]).all() and 0.0 <= got["color"].min() and got["color"].max() <= 1.0 + 1e-6
