@@ -1635,19 +1635,20 @@ void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   }
 }
 
-// Rays a persistent traversal launch set aside (degenerate direction): the reference's own traversal order
-// with its exact box tests (ray_mesh).  One workgroup; the list is almost always empty.
-// Capped at 32 VGPRs (the rest lives in scratch): the launch is almost always empty, but it sits in the
-// dependency chain of every bounce, and with 68 registers its one wavefront could not be placed while another
-// stream's persistent traversal wavefronts (5 x 96 registers per SIMD) held the chip -- it waited ~1 ms per bounce.
+// Rays a persistent traversal launch set aside (a direction with a zero / subnormal component, or a winner whose
+// parent box the ray only grazes): redone with EXACT box decisions -- the culled near-first walk of variants 1
+// and 2 (mesh_closest_wide: every inner box decided like the reference's ray_aabb, also for NaN / infinite
+// slab terms), which returns the reference's hit in ~50 box tests instead of the ~125 (worst case thousands)
+// of the reference's own order.  One workgroup; the list is almost always empty.
 template <bool kFirst>
 __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_index, DPaths paths, DHits hits,
                                                      const uint32_t* slow_list, DeviceCounters* counters, int bounce)
 {
-  __shared__ uint32_t s_stack[kStackDepth * kWave];
+  __shared__ uint32_t s_stack[kWideStack * kWave];
   const uint32_t count = counters->slow_count;
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
+  const uint32_t tri_base = sc.object_tri_base[obj_index];
   uint32_t flags = 0u;
   for (uint32_t i = threadIdx.x; i < count; i += kWave) {
     const uint32_t slot = slow_list[i];
@@ -1656,17 +1657,20 @@ __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_ind
       const float carried = hits.tp[slot].x;
       if (carried >= 0.0f) ray.tmax = carried;
     }
-    Hit rec;
-    rec.t = 0.0f;
-    rec.p = rec.n = mk3(0.f, 0.f, 0.f);
-    rec.mat = 0u;
-    rec.side = 0u;
+    float best_t = ray.tmax;
+    int best_k = -1;
     Tally unused;
     // the object's world box first (path_tracer.cu:84): the persistent kernels test it only for their winners
-    if (ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax)) &&
-        ray_mesh<false>(ray, sc, obj, rec, s_stack + threadIdx.x, flags, unused)) {
-      hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
-      hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(mat | (rec.side << 31)));
+    if (ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax)))
+      mesh_closest_wide<false>(ray, sc, obj, tri_base, best_t, best_k, s_stack + threadIdx.x, flags, unused);
+    if (best_k >= 0) {
+      const float4 tc = sc.tris[3u * ((size_t)tri_base + (uint32_t)best_k) + 2u];
+      const f3 outward = mk3(tc.y, tc.z, tc.w);
+      const f3 p = ray.o + ray.d * best_t;
+      const uint32_t side = dot(ray.d, outward) < 0.0f ? 0u : 1u;
+      const f3 nn = side == 0u ? outward : -outward;
+      hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
+      hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
     } else if (kFirst) {
       hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
     }
