@@ -241,7 +241,7 @@ def main():
     if rank == 0:
         value = rays / elapsed / 1e6
         line = {
-            "metric": "Mrays/s at 1920x1080, 8 bounces", "value": round(value, 3), "unit": "Mrays/s",
+            "metric": "Mrays/s at 1920\u00d71080, 8 bounces", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
