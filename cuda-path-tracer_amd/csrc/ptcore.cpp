@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -818,8 +819,13 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         }
         ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
         if (int rc = timed_begin(tl)) return rc;
+        // persistent wavefronts for this launch: about 48 ray batches of 64 per wavefront at the first bounce (a
+        // wavefront that gets only a few batches spends its life draining), at least 1024, at most the
+        // configured number (what is resident; the stack overflow areas are sized for it)
+        const uint64_t rays0 = (uint64_t)sl.bi.count * ctx->pix_count;
+        const uint32_t waves = (uint32_t)std::min<uint64_t>(ctx->traverse_waves, std::max<uint64_t>(1024u, (rays0 / 3072u + 7u) & ~7ull));
         launch_traverse(sl.stream, scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
-                        ctx->count_tests, ctx->traverse_waves, ctx->trace_variant, sl.slow_list, sl.bi);
+                        ctx->count_tests, waves, ctx->trace_variant, sl.slow_list, sl.bi);
         if (int rc = timed_end(tl)) return rc;
         if (ctx->trace_variant >= 3) launch_slow_rays(sl.stream, scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters, bounce);
       } else {
