@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")  # ORACLE_LIB: sanitizer build (oracle/Makefile)
 
 
 class OScene(C.Structure):
