@@ -1332,9 +1332,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
         const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
         const f3 h = cross(rd, e2);
         const float a = dot(e1, h);
+        // keep the first vertex's load with the other two (the compiler otherwise sinks it below the test of
+        // `a`, a second dependent memory round trip per leaf)
+        const f3 sv = ro - p0;
+        asm volatile("" ::"v"(sv.x), "v"(sv.y), "v"(sv.z));
         if (!(a > -0.0000001f && a < 0.0000001f)) {
           const float f = 1.0f / a;
-          const f3 sv = ro - p0;
           const float u = f * dot(sv, h);
           if (!(u < 0.0f || u > 1.0f)) {
             const f3 qv = cross(sv, e1);
