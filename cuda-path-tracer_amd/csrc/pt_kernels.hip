@@ -1103,6 +1103,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
     }
     ++sp;
   };
+  // the top entry without removing it (kNoChild for an empty stack)
+  auto peek = [&]() -> uint32_t {
+    const int top = sp - 1;
+    uint32_t r = stack[min(max(top, 0), kLds4 - 1) * kWave];
+    if (__builtin_expect(top >= kLds4, 0)) r = sc.spill[(size_t)(top - kLds4) * sc.spill_stride + gid].x;
+    return top >= 0 ? r : kNoChild;
+  };
   auto pop = [&]() -> uint32_t {
     if (sp == 0) return kNoChild;
     --sp;
@@ -1270,6 +1277,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       const float4 fy = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_y) ^ kFarY));
       const float4 fz = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_z) ^ kFarZ));
       const float4 rf = *reinterpret_cast<const float4*>(node_bytes + (nb | 96u));
+      // the entry a node without a hit child falls back to (nothing is pushed in that case): read from LDS while
+      // the node is on its way
+      const uint32_t below = peek();
       float key[4];
       uint32_t ref[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
       const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, nya[4] = {ny.x, ny.y, ny.z, ny.w}, nza[4] = {nz.x, nz.y, nz.z, nz.w};
@@ -1318,7 +1328,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
         if (key[2] < __builtin_inff()) push(ref[2]);
         if (key[1] < __builtin_inff()) push(ref[1]);
       }
-      cur = key[0] < __builtin_inff() ? ref[0] : pop();
+      if (key[0] < __builtin_inff()) {
+        cur = ref[0];
+      } else {
+        cur = below;
+        sp = sp > 0 ? sp - 1 : 0;
+      }
     }
     const uint64_t pend_mask = __ballot(active && pend != kNoChild);
     const uint64_t node_mask = __ballot(active && cur != kNoChild && !(cur & kLeafBit));
