@@ -1075,6 +1075,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   const char* node_bytes = reinterpret_cast<const char*>(sc.bvh4);
   // more wavefronts than batches (the margin keeps every wavefront that owns a static batch, see BatchFeed)
   if (blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
+  // the object's world box: the same for every ray of the launch (scalar registers)
+  auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
+  const f3 obj_bmin = mk3(uni(obj->bmin[0]), uni(obj->bmin[1]), uni(obj->bmin[2]));
+  const f3 obj_bmax = mk3(uni(obj->bmax[0]), uni(obj->bmax[1]), uni(obj->bmax[2]));
   BatchFeed feed;
   feed.init(counters, bi, bounce, work_slot, sc.static_eighths);
   uint32_t priv_next = 0u, priv_end = 0u;
@@ -1133,17 +1137,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   // cheap sufficient form (approximate arithmetic with the error bound held against the ray); the exact
   // divisions run only for rays that graze a box.
   auto finalize = [&]() {
+    // everything a winner needs from memory -- its parent's box, its normal -- requested in one go (three
+    // dependent round trips otherwise: this code runs every few loop iterations)
+    const size_t win = (size_t)max(best_k, 0);
+    const float4 pb0 = sc.leaf_parent[2u * win], pb1 = sc.leaf_parent[2u * win + 1u];
+    const float4 tc = tris[3u * win + 2u];
     if (best_k >= 0) {
       // world box (ray_aabb, intersections.cuh:87-103): quotients by reciprocal, each within 3 ulp of the quotient
-      const f3 bmin = ld3(obj->bmin), bmax = ld3(obj->bmax);
+      const f3 bmin = obj_bmin, bmax = obj_bmax;
       const f3 winv = mk3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
       const f3 a0 = (bmin - ro) * winv, a1 = (bmax - ro) * winv;
       const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
       const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
       const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
       bool world_sure = box_ok && finite_f(winv.x + winv.y + winv.z) && (wf - wn) > 2e-6f * (fabsf(wf) + fabsf(wn));
-      const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
       const bool parent_sure = surely_inside(xyz(pb0), xyz(pb1));
+      asm volatile("" ::"v"(tc.y), "v"(tc.z), "v"(tc.w));  // keeps the normal's load up there with the box's
       if (__builtin_expect(!(world_sure && parent_sure) || sc.force_slow == 2u, 0)) {
         if (!ray_aabb(ro, rd, bmin, bmax)) {
           best_k = -1;  // the reference skips the object: the carried hit (or the miss) stands
@@ -1159,7 +1168,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       }
     }
     if (best_k >= 0) {
-      const float4 tc = tris[3u * (size_t)best_k + 2u];
       const f3 outward = mk3(tc.y, tc.z, tc.w);
       const f3 p = ro + rd * best_t;
       const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
