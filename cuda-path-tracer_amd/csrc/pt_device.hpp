@@ -46,10 +46,13 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, n.xyz}   with p = transform_point(M, position),
 //           e1 = p1 - p0, e2 = p2 - p0, n = normalize(cross(e1, e2))   (exactly what the reference
 //           recomputes per test, path_tracer.cu:57-59, intersections.cuh:45-46,54-55)
-//   bvh4: the same tree collapsed to four children per node for the persistent traversal, 128 bytes per node
-//         (one cache line), component-major so four boxes are tested with vector code:
-//           q0..q2 = child min x / y / z [4]   q3..q5 = child max x / y / z [4]   q6 = refs[4]   q7 = unused
-//         ref = node index, kLeafBit | depth-first triangle rank, or kNoChild.  Nodes in depth-first preorder.
+//   bvh4q: the same tree collapsed to four children per node for the persistent traversal, 64 bytes per node
+//         (half a cache line, four 16-byte loads): dwords 0-2 origin xyz (f32); dword 3 = exponents of the three
+//         power-of-two grid steps (one byte per axis, IEEE biased); dwords 4-9 = child planes as 8-bit grid
+//         coordinates, component-major (lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4] hi_z[4], child c in byte c), rounded
+//         outwards: a quantised child box contains the exact one, which is all a conservative walk needs;
+//         dwords 12-15 = refs[4].  ref = node index, kLeafBit | depth-first triangle rank, or kNoChild.
+//         Nodes in depth-first preorder.
 //   leaf_parent: per triangle (depth-first rank) the box of the leaf's parent in the REFERENCE tree, 2 float4.
 //         Why it suffices for exactness: boxes nest exactly (parent = componentwise min/max of children) and
 //         IEEE subtraction/division are monotonic, so whenever a node passes the reference's box test all its
@@ -68,8 +71,8 @@ struct DScene {
   const float4* wide;              // 4 float4 per inner node
   const float4* tris;              // 3 float4 per instance triangle
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
-  const float4* bvh4;              // 8 float4 per four-wide node
   const float4* leaf_parent;       // 2 float4 per triangle
+  const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
   uint32_t spill_cap;              // entries per thread in `spill`

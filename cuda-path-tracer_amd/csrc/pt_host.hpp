@@ -34,7 +34,10 @@ int build_wide(const ptc_bvh_node* nodes, uint32_t count, WideAccel& out);
 
 // Four-wide collapse of the reference tree for the persistent traversal (see DScene::bvh4 in pt_device.hpp).
 struct Wide4Accel {
-  std::vector<float4> nodes;        // 8 per node, depth-first preorder
+  // Nodes of 64 bytes (16 dwords each), depth-first preorder: origin xyz (f32) | exponents of the three
+  // power-of-two grid steps | child planes as 8-bit grid coordinates, SoA (lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4]
+  // hi_z[4]), rounded outwards so that every quantised child box contains the exact one | 2 pad | the four child refs
+  std::vector<uint32_t> nodes_q;
   std::vector<float4> leaf_parent;  // 2 per triangle (depth-first leaf order): box of the leaf's parent node
   uint32_t root_ref = 0;
   uint32_t depth = 0;               // levels of four-wide nodes above the deepest leaf

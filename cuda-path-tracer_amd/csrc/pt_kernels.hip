@@ -1072,7 +1072,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
-  const char* node_bytes = reinterpret_cast<const char*>(sc.bvh4);
   // more wavefronts than batches (the margin keeps every wavefront that owns a static batch, see BatchFeed)
   if (blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
   // the object's world box: the same for every ray of the launch (scalar registers)
@@ -1090,10 +1089,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   int sp = 0, best_k = -1;
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
-  // byte offsets of the near plane of each axis inside a node (lo_x 0, lo_y 16, lo_z 32, hi = lo + 48); the
-  // far plane's offset is the near one ^ kFarX/Y/Z
-  uint32_t near_x = 0u, near_y = 16u, near_z = 32u;
-  constexpr uint32_t kFarX = 0u ^ 48u, kFarY = 16u ^ 64u, kFarZ = 32u ^ 80u;
+  bool neg_x = false, neg_y = false, neg_z = false;  // sign of 1/d per axis: which plane of a box is the near one
   float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
   Tally tally;
   uint32_t ray_boxes = 0u;
@@ -1124,7 +1120,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   // the conservative slab pair of one box for this lane's ray, tolerance folded INWARDS: if even that interval is
   // non-empty, the reference's exact test of the box passes
   auto surely_inside = [&](const f3 lo, const f3 hi) -> bool {
-    const bool nx = near_x != 0u, ny = near_y != 16u, nz = near_z != 32u;
+    const bool nx = neg_x, ny = neg_y, nz = neg_z;
     const float tn = fmaxf(fmaxf(__builtin_fmaf(nx ? hi.x : lo.x, inv.x, oif.x), __builtin_fmaf(ny ? hi.y : lo.y, inv.y, oif.y)),
                            __builtin_fmaf(nz ? hi.z : lo.z, inv.z, oif.z));
     const float tf = fminf(fminf(__builtin_fmaf(nx ? lo.x : hi.x, inv.x, oin.x), __builtin_fmaf(ny ? lo.y : hi.y, inv.y, oin.y)),
@@ -1239,9 +1235,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
           } else {
             oin = oi - tol;
             oif = oi + tol;
-            near_x = inv.x < 0.0f ? 48u : 0u;
-            near_y = inv.y < 0.0f ? 64u : 16u;
-            near_z = inv.z < 0.0f ? 80u : 32u;
+            neg_x = inv.x < 0.0f;
+            neg_y = inv.y < 0.0f;
+            neg_z = inv.z < 0.0f;
             best_t = t_in;
             best_k = -1;
             limit = scale * best_t * 1.001f;
@@ -1276,35 +1272,38 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       cur = pop();
     }
     if (active && cur != kNoChild && !(cur & kLeafBit)) {
-      // near / far plane of each axis straight from its place in the node (chosen by the sign of 1/d)
-      const uint32_t nb = cur << 7;
-      const float4 nx = *reinterpret_cast<const float4*>(node_bytes + (nb | near_x));
-      const float4 ny = *reinterpret_cast<const float4*>(node_bytes + (nb | near_y));
-      const float4 nz = *reinterpret_cast<const float4*>(node_bytes + (nb | near_z));
-      const float4 fx = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_x) ^ kFarX));
-      const float4 fy = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_y) ^ kFarY));
-      const float4 fz = *reinterpret_cast<const float4*>(node_bytes + ((nb | near_z) ^ kFarZ));
-      const float4 rf = *reinterpret_cast<const float4*>(node_bytes + (nb | 96u));
+      // 64-byte node: origin + power-of-two grid steps + 8-bit plane coordinates (Wide4Accel::nodes_q).  A plane
+      // is origin + q * step, so its slab term is fma(q, step / d, fma(origin, 1/d, -o/d -+ tol)): two terms per
+      // axis and node, one fma per plane.  The quantised boxes contain the exact ones, so the walk stays
+      // conservative; the exact tests of the winner use the exact parent box (leaf_parent) as before.
+      const uint4* qn = sc.bvh4q + 4u * (size_t)cur;
+      const uint4 q0 = qn[0], q1 = qn[1];
+      const uint2 q2 = *reinterpret_cast<const uint2*>(qn + 2);
+      const uint4 q3 = qn[3];
       // the entry a node without a hit child falls back to (nothing is pushed in that case): read from LDS while
       // the node is on its way
       const uint32_t below = peek();
+      const f3 org = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+      const f3 ax = mk3(__uint_as_float((q0.w & 0xffu) << 23) * inv.x, __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * inv.y,
+                        __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * inv.z);
+      const f3 bn = mk3(__builtin_fmaf(org.x, inv.x, oin.x), __builtin_fmaf(org.y, inv.y, oin.y), __builtin_fmaf(org.z, inv.z, oin.z));
+      const f3 bf = mk3(__builtin_fmaf(org.x, inv.x, oif.x), __builtin_fmaf(org.y, inv.y, oif.y), __builtin_fmaf(org.z, inv.z, oif.z));
+      const bool ngx = neg_x, ngy = neg_y, ngz = neg_z;
+      const uint32_t nqx = ngx ? q1.w : q1.x, fqx = ngx ? q1.x : q1.w;
+      const uint32_t nqy = ngy ? q2.x : q1.y, fqy = ngy ? q1.y : q2.x;
+      const uint32_t nqz = ngz ? q2.y : q1.z, fqz = ngz ? q1.z : q2.y;
       float key[4];
-      uint32_t ref[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
-      const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, nya[4] = {ny.x, ny.y, ny.z, ny.w}, nza[4] = {nz.x, nz.y, nz.z, nz.w};
-      const float fxa[4] = {fx.x, fx.y, fx.z, fx.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
+      uint32_t ref[4] = {q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        // tn is a lower bound of the true entry distance and tf an upper bound of the true exit distance (the
-        // tolerance is inside oin / oif), so the child can be skipped when the interval [max(tn, 0), min(tf,
-        // limit)] is empty: box missed, box behind the origin (every t in it < 0 < t_min), or box beyond the
-        // closest hit so far (limit carries a 0.1 % margin; ties at equal t start no farther than the hit).
-        // An unused child slot holds the empty box (+inf, -inf): never taken.
-        const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nxa[c], inv.x, oin.x), __builtin_fmaf(nya[c], inv.y, oin.y)),
-                                     __builtin_fmaf(nza[c], inv.z, oin.z)), 0.0f);
-        const float tf = fminf(fminf(fminf(__builtin_fmaf(fxa[c], inv.x, oif.x), __builtin_fmaf(fya[c], inv.y, oif.y)),
-                                     __builtin_fmaf(fza[c], inv.z, oif.z)), limit);
+        const float cnx = (float)((nqx >> (8 * c)) & 0xffu), cny = (float)((nqy >> (8 * c)) & 0xffu), cnz = (float)((nqz >> (8 * c)) & 0xffu);
+        const float cfx = (float)((fqx >> (8 * c)) & 0xffu), cfy = (float)((fqy >> (8 * c)) & 0xffu), cfz = (float)((fqz >> (8 * c)) & 0xffu);
+        const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(cnx, ax.x, bn.x), __builtin_fmaf(cny, ax.y, bn.y)),
+                                     __builtin_fmaf(cnz, ax.z, bn.z)), 0.0f);
+        const float tf = fminf(fminf(fminf(__builtin_fmaf(cfx, ax.x, bf.x), __builtin_fmaf(cfy, ax.y, bf.y)),
+                                     __builtin_fmaf(cfz, ax.z, bf.z)), limit);
         if (kCount && ref[c] != kNoChild) { ++tally.boxes; ++ray_boxes; }
-        key[c] = tn <= tf ? tn : __builtin_inff();
+        key[c] = (ref[c] != kNoChild && tn <= tf) ? tn : __builtin_inff();
       }
       // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
       auto cx = [&](int a, int b) {

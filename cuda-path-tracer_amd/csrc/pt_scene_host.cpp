@@ -2,6 +2,7 @@
 #include "pt_host.hpp"
 #include "pt_device.hpp"
 
+#include <cmath>
 #include <limits>
 #include <cfloat>
 #include <algorithm>
@@ -208,12 +209,63 @@ struct Collapse {
     return 2.0f * (dx * dy + dx * dz + dy * dz);
   }
 
+  // 64-byte form of node idx (Wide4Accel::nodes_q).  Grid: origin = the node's lower corner, step 2^e per axis with
+  // 255 steps covering the node's extent; a child's lower planes round down, its upper planes up (checked in
+  // double precision, where origin + q * step is exact), so the walk over these boxes stays conservative.
+  void quantise(uint32_t idx, int nk, const float lo[3][4], const float hi[3][4], const uint32_t refs[4])
+  {
+    uint32_t* q = &out.nodes_q[(size_t)idx * 16u];
+    uint32_t exps = 0u;
+    for (int a = 0; a < 3; ++a) {
+      float origin = std::numeric_limits<float>::infinity(), top = -std::numeric_limits<float>::infinity();
+      for (int k = 0; k < nk; ++k) {
+        origin = std::min(origin, lo[a][k]);
+        top = std::max(top, hi[a][k]);
+      }
+      const double extent = (double)top - (double)origin;
+      int e = -126;
+      if (extent > 0.0) {
+        e = (int)std::ceil(std::log2(extent / 255.0));
+        e = std::max(-126, std::min(127, e));
+      }
+      for (;;) {  // grow the step until every plane fits 0..255 (one pass almost always)
+        const double step = std::ldexp(1.0, e);
+        bool ok = true;
+        uint32_t lo_q = 0u, hi_q = 0u;
+        for (int k = 0; k < 4; ++k) {
+          uint32_t ql = 0u, qh = 0u;
+          if (k < nk) {
+            const double fl = std::floor(((double)lo[a][k] - (double)origin) / step);
+            const double ce = std::ceil(((double)hi[a][k] - (double)origin) / step);
+            if (fl < 0.0 || ce > 255.0 || fl > 255.0) ok = false;
+            ql = (uint32_t)std::max(0.0, std::min(255.0, fl));
+            qh = (uint32_t)std::max(0.0, std::min(255.0, ce));
+            if ((double)origin + ql * step > (double)lo[a][k] || (double)origin + qh * step < (double)hi[a][k]) ok = false;
+          }
+          lo_q |= ql << (8 * k);
+          hi_q |= qh << (8 * k);
+        }
+        if (ok || e >= 127) {
+          q[4 + a] = lo_q;
+          q[7 + a] = hi_q;
+          break;
+        }
+        ++e;
+      }
+      std::memcpy(&q[a], &origin, 4);
+      exps |= (uint32_t)(e + 127) << (8 * a);
+    }
+    q[3] = exps;
+    q[10] = q[11] = 0u;
+    for (int k = 0; k < 4; ++k) q[12 + k] = refs[k];
+  }
+
   // returns the child reference of reference-tree node i
   uint32_t emit(uint32_t i, uint32_t level)
   {
     if (nodes[i].primitive_count != 0u) return kLeafBit | leaf_rank[i];
-    const uint32_t idx = (uint32_t)(out.nodes.size() / 8u);
-    out.nodes.resize(out.nodes.size() + 8u);
+    const uint32_t idx = (uint32_t)(out.nodes_q.size() / 16u);
+    out.nodes_q.resize(out.nodes_q.size() + 16u, 0u);
     deepest = std::max(deepest, level + 1u);
     // children: start with the two children, open the inner child with the largest surface area until four;
     // a child is replaced IN PLACE by (left, right) so the left-to-right order stays the depth-first order
@@ -246,25 +298,11 @@ struct Collapse {
         }
         refs[k] = emit(kids[k], level + 1u);
       } else {
-        for (int a = 0; a < 3; ++a) {  // the empty box: every slab test of it fails (k_traverse4)
-          lo[a][k] = std::numeric_limits<float>::infinity();
-          hi[a][k] = -std::numeric_limits<float>::infinity();
-        }
-        refs[k] = kNoChild;
+        for (int a = 0; a < 3; ++a) lo[a][k] = hi[a][k] = 0.0f;
+        refs[k] = kNoChild;  // unused slot: the kernel skips it by its reference
       }
     }
-    auto bits = [](uint32_t u) {
-      float f;
-      std::memcpy(&f, &u, 4);
-      return f;
-    };
-    float4* w = &out.nodes[(size_t)idx * 8u];
-    for (int a = 0; a < 3; ++a) {
-      w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
-      w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
-    }
-    w[6] = make_float4(bits(refs[0]), bits(refs[1]), bits(refs[2]), bits(refs[3]));
-    w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    quantise(idx, nk, lo, hi, refs);
     return idx;
   }
 };
@@ -305,11 +343,11 @@ int build_wide4(const ptc_bvh_node* nodes, uint32_t count, Wide4Accel& out)
       }
     }
   }
-  out.nodes.reserve((size_t)count / 2u * 8u);
+  out.nodes_q.reserve((size_t)count / 2u * 16u);
   Collapse c{nodes, leaf_rank, out};
   out.root_ref = c.emit(0u, 0u);
   out.depth = c.deepest;
-  out.node_count = (uint32_t)(out.nodes.size() / 8u);
+  out.node_count = (uint32_t)(out.nodes_q.size() / 16u);
   return PTC_OK;
 }
 

@@ -468,8 +468,12 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
   Wide4Accel w4;
   if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh4, w4.nodes.data(), w4.nodes.size())) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
+  {
+    const uint32_t* q = nullptr;
+    if (int rc = upload(ctx, ctx->scene_allocs, &q, w4.nodes_q.data(), w4.nodes_q.size())) return rc;
+    d.bvh4q = reinterpret_cast<const uint4*>(q);
+  }
   d.bvh4_root = w4.root_ref;
   d.refill_lanes = ctx->refill_lanes;
   d.leaf_batch = ctx->leaf_batch;
