@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = streams x the batch size")
     ap.add_argument("--batch-frames", type=int, default=0,
                     help="frames traced per launch; 0 = up to 32, chosen so that the timed steps split evenly over the streams")
-    ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 on one GPU, 4 per rank on several")
+    ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
@@ -107,9 +107,10 @@ def main():
     # Schedule: `batch` consecutive frames share every launch (the latency tail of a bounce -- a few long rays --
     # and the drain of the persistent wavefronts are paid once per batch) and `streams` batches are in flight so
     # that the small kernels and the tail of one overlap the bulk of another.  A rank that owns 1/N of the rows
-    # has 1/N of the rays per launch and keeps 4 batches in flight.  Results do not depend on any of it
+    # has 1/N of the rays per launch and, from N = 4 on, keeps 4 smaller batches in flight (measured on 1/2, 1/4 and
+    # 1/8 shares of the rows on one GPU).  Results do not depend on any of it
     # (tests/test_gpu_schedules.py).
-    streams = args.streams or (2 if world == 1 else 4)
+    streams = args.streams or (2 if world <= 2 else 4)
     if args.batch_frames:
         batch = args.batch_frames
     else:
@@ -120,8 +121,8 @@ def main():
     pt.set_param("frames_in_flight", args.frames_in_flight)
     pt.set_param("batch_frames", batch)
     # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU (a second launch's
-    # wavefronts move in as the first one's drain); half of that for the smaller launches of a multi-GPU rank
-    pt.set_param("traverse_waves", 5120 if world == 1 else 2560)
+    # wavefronts move in as the first one's drain); half of that for the smaller launches of a rank among 4 or 8
+    pt.set_param("traverse_waves", 5120 if world <= 2 else 2560)
     pt.create_buffers((W, H), flat)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
