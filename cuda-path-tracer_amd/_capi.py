@@ -125,6 +125,7 @@ SIGNATURES = {
                                  C.POINTER(ptc_bvh_node), C.POINTER(C.c_uint32)]),
     "ptc_make_object": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(ptc_sphere),
                                    C.POINTER(C.c_float), C.POINTER(ptc_object)]),
+    "ptc_check_traversal_layout": (C.c_int, [C.POINTER(ptc_bvh_node), C.c_uint32, C.POINTER(C.c_uint64)]),
     "ptc_selftest_math": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }

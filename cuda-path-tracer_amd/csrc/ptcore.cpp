@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pt_device.hpp"
@@ -1242,6 +1243,119 @@ int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_s
                     ptc_object* out)
 {
   return make_object(type, index, m16, sphere, mesh_aabb6, out);
+}
+
+int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, uint64_t* checked_boxes)
+{
+  if (!nodes || node_count == 0u) return PTC_ERR_INVALID;
+  Wide4Accel w4;
+  if (int rc = build_wide4(nodes, node_count, w4)) return rc;
+  // the reference tree: leaf of every depth-first rank, parents, and every node's range of leaf ranks
+  std::vector<uint32_t> leaf_of_rank, parent(node_count, 0xffffffffu), first_rank(node_count, 0u), last_rank(node_count, 0u);
+  {
+    std::vector<uint32_t> stack{0u};
+    while (!stack.empty()) {
+      const uint32_t i = stack.back();
+      stack.pop_back();
+      if (nodes[i].primitive_count != 0u) {
+        first_rank[i] = last_rank[i] = (uint32_t)leaf_of_rank.size();
+        leaf_of_rank.push_back(i);
+      } else {
+        const uint32_t l = nodes[i].first_child_or_primitive;
+        if (l + 1u >= node_count) return PTC_ERR_BVH;
+        parent[l] = parent[l + 1u] = i;
+        stack.push_back(l + 1u);
+        stack.push_back(l);
+      }
+    }
+    for (uint32_t i = node_count; i-- > 0u;)  // children come after their parent in the reference's array
+      if (nodes[i].primitive_count == 0u) {
+        first_rank[i] = first_rank[nodes[i].first_child_or_primitive];
+        last_rank[i] = last_rank[nodes[i].first_child_or_primitive + 1u];
+      }
+  }
+  std::unordered_map<uint64_t, uint32_t> node_of_range;
+  node_of_range.reserve(node_count * 2u);
+  for (uint32_t i = 0; i < node_count; ++i) node_of_range[((uint64_t)first_rank[i] << 32) | last_rank[i]] = i;
+
+  int bad = 0;
+  uint64_t boxes = 0;
+  const uint32_t triangles = (uint32_t)leaf_of_rank.size();
+  std::vector<uint32_t> seen(triangles, 0u);
+  if (w4.root_ref & pt::kLeafBit) {
+    if (triangles != 1u || (w4.root_ref & ~pt::kLeafBit) != 0u) ++bad;
+    else seen[0] = 1u;
+  } else {
+    const uint32_t n4 = (uint32_t)(w4.nodes_q.size() / 16u);
+    // rank range of every four-wide node: children are in depth-first order and nodes in depth-first preorder,
+    // so a child node has a larger index than its parent
+    std::vector<uint32_t> first4(n4, 0u), last4(n4, 0u);
+    for (uint32_t n = n4; n-- > 0u;) {
+      const uint32_t* q = &w4.nodes_q[(size_t)n * 16u];
+      bool any = false;
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t ref = q[12 + c];
+        if (ref == pt::kNoChild) continue;
+        uint32_t a, b;
+        if (ref & pt::kLeafBit) {
+          a = b = ref & ~pt::kLeafBit;
+        } else {
+          if (ref <= n || ref >= n4) return PTC_ERR_BVH;
+          a = first4[ref];
+          b = last4[ref];
+        }
+        if (!any) first4[n] = a;
+        else if (a != last4[n] + 1u) ++bad;  // the children tile their parent's leaves in order
+        last4[n] = b;
+        any = true;
+      }
+      if (!any) ++bad;
+    }
+    if (w4.root_ref >= n4 || first4[w4.root_ref] != 0u || last4[w4.root_ref] + 1u != triangles) ++bad;
+    for (uint32_t n = 0; n < n4 && w4.root_ref < n4; ++n) {
+      const uint32_t* q = &w4.nodes_q[(size_t)n * 16u];
+      float origin[3];
+      std::memcpy(origin, q, 12);
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t ref = q[12 + c];
+        if (ref == pt::kNoChild) continue;
+        uint32_t a, b;
+        if (ref & pt::kLeafBit) {
+          a = b = ref & ~pt::kLeafBit;
+          if (a < triangles) ++seen[a];
+        } else {
+          a = first4[ref];
+          b = last4[ref];
+        }
+        const auto it = node_of_range.find(((uint64_t)a << 32) | b);
+        if (it == node_of_range.end()) {  // the child does not stand for a node of the reference tree
+          ++bad;
+          continue;
+        }
+        const ptc_bvh_node& x = nodes[it->second];
+        for (int ax = 0; ax < 3; ++ax) {
+          const double step = std::ldexp(1.0, (int)((q[3] >> (8 * ax)) & 0xffu) - 127);
+          const double lo = (double)origin[ax] + (double)((q[4 + ax] >> (8 * c)) & 0xffu) * step;
+          const double hi = (double)origin[ax] + (double)((q[7 + ax] >> (8 * c)) & 0xffu) * step;
+          if (lo > (double)x.aabb_min[ax] || hi < (double)x.aabb_max[ax]) ++bad;
+        }
+        ++boxes;
+      }
+    }
+  }
+  for (uint32_t r = 0; r < triangles; ++r) {
+    if (seen[r] != 1u) ++bad;  // every triangle is a child of exactly one four-wide node
+    const uint32_t leaf = leaf_of_rank[r];
+    if (parent[leaf] != 0xffffffffu) {
+      const float4 p0 = w4.leaf_parent[2u * (size_t)r], p1 = w4.leaf_parent[2u * (size_t)r + 1u];
+      const ptc_bvh_node& p = nodes[parent[leaf]];
+      if (p0.x != p.aabb_min[0] || p0.y != p.aabb_min[1] || p0.z != p.aabb_min[2] || p1.x != p.aabb_max[0] ||
+          p1.y != p.aabb_max[1] || p1.z != p.aabb_max[2])
+        ++bad;
+    }
+  }
+  if (checked_boxes) *checked_boxes = boxes;
+  return bad;
 }
 
 int ptc_selftest_math(ptc_ctx* ctx, const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt,

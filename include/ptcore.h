@@ -280,6 +280,14 @@ int ptc_build_bvh(const float* positions, uint32_t vertex_count, const uint32_t*
 int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_sphere* sphere,
                     const float* mesh_aabb6, ptc_object* out);
 
+/* Host-side check of the traversal layouts derived from a reference BVH (no GPU needed): builds the collapsed
+ * four-wide tree with its 64-byte quantised nodes and verifies, in double precision, that every quantised child
+ * box contains the exact box of the reference node it stands for, that every reference leaf is reachable exactly
+ * once, and that each triangle's recorded parent box is its reference parent's.  Returns the number of
+ * violations (0 = sound), or a negative ptc_status; *checked_boxes (may be NULL) gets the number of child boxes
+ * looked at. */
+int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, uint64_t* checked_boxes);
+
 /* Device self-test of the arithmetic contract the parity tests rely on: evaluates IEEE divide,
  * sqrt and the deterministic sin/cos on the GPU for n inputs (host arrays in, host arrays out). */
 int ptc_selftest_math(ptc_ctx* ctx, const float* a, const float* b, uint32_t n, float* out_div,

@@ -68,6 +68,37 @@ def test_host_bvh_builder_equals_oracle(pkg, orc, mesh_name):
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
 
 
+@pytest.mark.parametrize("mesh_name", ["grid33x17", "sphere24x48", "grid_ties", "grid257x129", "one_triangle", "thin"])
+def test_traversal_layout_is_sound(pkg, mesh_name):
+    """The default traversal walks a four-wide collapse of the reference BVH with 64-byte quantised nodes.  It only
+    has to be conservative, so the invariant is containment: every quantised child box contains the exact box of the
+    reference node it stands for (checked in double precision), the children of a node tile its leaves in
+    depth-first order, every triangle hangs under exactly one node, and the recorded parent boxes are the
+    reference's.  Host-side, no GPU."""
+    import ctypes as C
+    mesh = {
+        "grid33x17": lambda: pkg.scenes.heightfield_mesh(33, 17, 8.0, 4.0, seed=7),
+        "sphere24x48": lambda: pkg.scenes.displaced_sphere_mesh(24, 48),
+        "grid_ties": lambda: pkg.Mesh(*_flat_grid(17, 9)),
+        "grid257x129": lambda: pkg.scenes.heightfield_mesh(257, 129, 8.0, 4.0, seed=3),
+        "one_triangle": lambda: pkg.Mesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32),
+                                         np.array([0, 1, 2], dtype=np.uint32)),
+        # extents that differ by 1e6 between the axes, far from the origin: a different grid step per axis
+        "thin": lambda: pkg.Mesh((pkg.scenes.heightfield_mesh(33, 17, 8.0, 4.0, seed=5).positions
+                                  * np.array([1000.0, 0.001, 1.0], dtype=np.float32)
+                                  + np.array([5000.0, -3.0, 77.0], dtype=np.float32)).astype(np.float32),
+                                 pkg.scenes.heightfield_mesh(33, 17, 8.0, 4.0, seed=5).indices),
+    }[mesh_name]()
+    nodes, _ = pkg.bvh_from_mesh(mesh)
+    checked = C.c_uint64(0)
+    arr = np.ascontiguousarray(nodes)
+    bad = pkg.lib().ptc_check_traversal_layout(arr.ctypes.data_as(C.POINTER(pkg._capi.ptc_bvh_node)), len(arr),
+                                                C.byref(checked))
+    assert bad == 0
+    tris = len(mesh.indices) // 3
+    assert checked.value >= tris or tris == 1   # every leaf is one of the child boxes (a lone triangle is the root)
+
+
 def _flat_grid(nx, nz):
     m_x, m_z = np.meshgrid(np.arange(nx, dtype=np.float32), np.arange(nz, dtype=np.float32), indexing="xy")
     pos = np.stack([m_x, 0.01 * ((m_x * 7 + m_z * 3) % 5), m_z], axis=-1).reshape(-1, 3)
