@@ -79,7 +79,6 @@ struct DScene {
   uint32_t bvh4_root;
   uint32_t force_slow;             // test hook: hand EVERY ray to k_slow_rays
   uint32_t static_eighths;         // persistent traversal: share (x/8) of each image region dealt without atomics
-  uint32_t leaf_batch;             // persistent traversal: run the triangle tests once this many lanes hold a leaf
   uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle
   float root_min[3];               // box of the root (tested before descending, like any inner node)
   float root_max[3];

@@ -1085,7 +1085,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   bool active = false;
   bool pending = false;
   uint32_t slot = 0u, cur = 0u, flags = 0u;
-  uint32_t pend = kNoChild;  // a leaf this lane has reached but not tested yet (triangle tests are batched)
   int sp = 0, best_k = -1;
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
@@ -1109,13 +1108,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
     uint32_t r = stack[min(max(top, 0), kLds4 - 1) * kWave];
     if (__builtin_expect(top >= kLds4, 0)) r = sc.spill[(size_t)(top - kLds4) * sc.spill_stride + gid].x;
     return top >= 0 ? r : kNoChild;
-  };
-  auto pop = [&]() -> uint32_t {
-    if (sp == 0) return kNoChild;
-    --sp;
-    uint32_t r = stack[min(sp, kLds4 - 1) * kWave];
-    if (__builtin_expect(sp >= kLds4, 0)) r = sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x;
-    return r;
   };
   // the conservative slab pair of one box for this lane's ray, tolerance folded INWARDS: if even that interval is
   // non-empty, the reference's exact test of the box passes
@@ -1242,7 +1234,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
             best_k = -1;
             limit = scale * best_t * 1.001f;
             cur = sc.bvh4_root;
-            pend = kNoChild;
             sp = 0;
             ray_boxes = 0u;
           }
@@ -1262,102 +1253,108 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       continue;
     }
 
-    // One loop iteration = at most one node step per lane.  A lane that reaches a leaf parks it in `pend` and
-    // goes on with its next stack entry; the triangle tests run once sc.leaf_batch lanes hold one (or nothing
-    // else can proceed).  Measured on the 1M-triangle scene: a threshold of 1 (test at once) is fastest --
-    // the triangle code then runs nearly every iteration with ~1/8 of the lanes, but batching 8..48 lanes
-    // delays the hit that prunes the rest of the walk and costs 5-30 %.
-    if (active && cur != kNoChild && (cur & kLeafBit) && pend == kNoChild) {
-      pend = cur;
-      cur = pop();
-    }
-    if (active && cur != kNoChild && !(cur & kLeafBit)) {
-      // 64-byte node: origin + power-of-two grid steps + 8-bit plane coordinates (Wide4Accel::nodes_q).  A plane
-      // is origin + q * step, so its slab term is fma(q, step / d, fma(origin, 1/d, -o/d -+ tol)): two terms per
-      // axis and node, one fma per plane.  The quantised boxes contain the exact ones, so the walk stays
-      // conservative; the exact tests of the winner use the exact parent box (leaf_parent) as before.
-      const uint4* qn = sc.bvh4q + 4u * (size_t)cur;
-      const uint4 q0 = qn[0], q1 = qn[1];
-      const uint2 q2 = *reinterpret_cast<const uint2*>(qn + 2);
-      const uint4 q3 = qn[3];
-      // the entry a node without a hit child falls back to (nothing is pushed in that case): read from LDS while
-      // the node is on its way
+    // One loop iteration = one step per lane, and ONE memory round trip: the lane's current reference is either a
+    // node or a leaf, both records are fetched by the SAME four 16-byte loads from a per-lane address (a 64-byte
+    // node, or a 48-byte triangle record whose last 16 bytes are simply requested twice), and the stack entry the
+    // lane falls back to is read from LDS meanwhile.  Vector-memory instructions and dependent round trips are
+    // what this loop is bound by (lesson x): four loads and one wait per iteration, where
+    // separate node and triangle phases needed seven loads and two waits.
+    if (active) {
+      const bool is_leaf = (cur & kLeafBit) != 0u;
+      const uint32_t index = cur & ~kLeafBit;
+      const char* rec = is_leaf ? reinterpret_cast<const char*>(tris) + 48u * (size_t)index
+                                : reinterpret_cast<const char*>(sc.bvh4q) + 64u * (size_t)index;
+      // The four loads are written as instructions: left to the compiler they are split by use (the leaf branch
+      // needs 36 of the 64 bytes), narrowed and partly sunk into the branches -- five to seven loads again.  The
+      // compiler does not count these in its s_waitcnt bookkeeping, so the wait is explicit and carries the four
+      // results as operands: nothing can read them before it.  (Loads return in order, so the compiler's own
+      // vmcnt waits elsewhere stay conservative.)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 w0, w1, w2, w3;
+      const char* rec3 = rec + (is_leaf ? 32 : 48);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w0) : "v"(rec));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(w1) : "v"(rec));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(w2) : "v"(rec));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w3) : "v"(rec3));
       const uint32_t below = peek();
-      const f3 org = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-      const f3 ax = mk3(__uint_as_float((q0.w & 0xffu) << 23) * inv.x, __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * inv.y,
-                        __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * inv.z);
-      const f3 bn = mk3(__builtin_fmaf(org.x, inv.x, oin.x), __builtin_fmaf(org.y, inv.y, oin.y), __builtin_fmaf(org.z, inv.z, oin.z));
-      const f3 bf = mk3(__builtin_fmaf(org.x, inv.x, oif.x), __builtin_fmaf(org.y, inv.y, oif.y), __builtin_fmaf(org.z, inv.z, oif.z));
-      const bool ngx = neg_x, ngy = neg_y, ngz = neg_z;
-      const uint32_t nqx = ngx ? q1.w : q1.x, fqx = ngx ? q1.x : q1.w;
-      const uint32_t nqy = ngy ? q2.x : q1.y, fqy = ngy ? q1.y : q2.x;
-      const uint32_t nqz = ngz ? q2.y : q1.z, fqz = ngz ? q1.z : q2.y;
-      float key[4];
-      uint32_t ref[4] = {q3.x, q3.y, q3.z, q3.w};
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+      const uint4 q0 = make_uint4(w0.x, w0.y, w0.z, w0.w), q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
+      const uint4 q2 = make_uint4(w2.x, w2.y, w2.z, w2.w), q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
+      if (!is_leaf) {
+        // 64-byte node: origin + power-of-two grid steps + 8-bit plane coordinates (Wide4Accel::nodes_q).  A plane
+        // is origin + q * step, so its slab term is fma(q, step / d, fma(origin, 1/d, -o/d -+ tol)): two terms per
+        // axis and node, one fma per plane.  The quantised boxes contain the exact ones, so the walk stays
+        // conservative; the exact tests of the winner use the exact parent box (leaf_parent) as before.
+        const f3 org = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        const f3 ax = mk3(__uint_as_float((q0.w & 0xffu) << 23) * inv.x, __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * inv.y,
+                          __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * inv.z);
+        const f3 bn = mk3(__builtin_fmaf(org.x, inv.x, oin.x), __builtin_fmaf(org.y, inv.y, oin.y), __builtin_fmaf(org.z, inv.z, oin.z));
+        const f3 bf = mk3(__builtin_fmaf(org.x, inv.x, oif.x), __builtin_fmaf(org.y, inv.y, oif.y), __builtin_fmaf(org.z, inv.z, oif.z));
+        const uint32_t nqx = neg_x ? q1.w : q1.x, fqx = neg_x ? q1.x : q1.w;
+        const uint32_t nqy = neg_y ? q2.x : q1.y, fqy = neg_y ? q1.y : q2.x;
+        const uint32_t nqz = neg_z ? q2.y : q1.z, fqz = neg_z ? q1.z : q2.y;
+        float key[4];
+        uint32_t ref[4] = {q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float cnx = (float)((nqx >> (8 * c)) & 0xffu), cny = (float)((nqy >> (8 * c)) & 0xffu), cnz = (float)((nqz >> (8 * c)) & 0xffu);
-        const float cfx = (float)((fqx >> (8 * c)) & 0xffu), cfy = (float)((fqy >> (8 * c)) & 0xffu), cfz = (float)((fqz >> (8 * c)) & 0xffu);
-        const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(cnx, ax.x, bn.x), __builtin_fmaf(cny, ax.y, bn.y)),
-                                     __builtin_fmaf(cnz, ax.z, bn.z)), 0.0f);
-        const float tf = fminf(fminf(fminf(__builtin_fmaf(cfx, ax.x, bf.x), __builtin_fmaf(cfy, ax.y, bf.y)),
-                                     __builtin_fmaf(cfz, ax.z, bf.z)), limit);
-        if (kCount && ref[c] != kNoChild) { ++tally.boxes; ++ray_boxes; }
-        key[c] = (ref[c] != kNoChild && tn <= tf) ? tn : __builtin_inff();
-      }
-      // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
-      auto cx = [&](int a, int b) {
-        const bool sw = key[b] < key[a];
-        const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
-        const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];
-        key[a] = ka;
-        key[b] = kb;
-        ref[a] = ra;
-        ref[b] = rb;
-      };
-      cx(0, 1);
-      cx(2, 3);
-      cx(0, 2);
-      cx(1, 3);
-      cx(1, 2);
-      // the others go on the stack, farthest first
-      if (__builtin_expect(sp + 3 <= kLds4, 1)) {
-        // room for all three in LDS: write unconditionally, advance only past the ones that count (a slot that
-        // does not count is overwritten by the next write or stays above the top)
-        stack[sp * kWave] = ref[3];
-        sp += key[3] < __builtin_inff() ? 1 : 0;
-        stack[sp * kWave] = ref[2];
-        sp += key[2] < __builtin_inff() ? 1 : 0;
-        stack[sp * kWave] = ref[1];
-        sp += key[1] < __builtin_inff() ? 1 : 0;
+        for (int c = 0; c < 4; ++c) {
+          // tn is a lower bound of the true entry distance and tf an upper bound of the true exit distance (the
+          // tolerance is inside oin / oif), so the child can be skipped when the interval [max(tn, 0), min(tf,
+          // limit)] is empty: box missed, box behind the origin (every t in it < 0 < t_min), or box beyond the
+          // closest hit so far (limit carries a 0.1 % margin; ties at equal t start no farther than the hit).
+          const float cnx = (float)((nqx >> (8 * c)) & 0xffu), cny = (float)((nqy >> (8 * c)) & 0xffu), cnz = (float)((nqz >> (8 * c)) & 0xffu);
+          const float cfx = (float)((fqx >> (8 * c)) & 0xffu), cfy = (float)((fqy >> (8 * c)) & 0xffu), cfz = (float)((fqz >> (8 * c)) & 0xffu);
+          const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(cnx, ax.x, bn.x), __builtin_fmaf(cny, ax.y, bn.y)),
+                                       __builtin_fmaf(cnz, ax.z, bn.z)), 0.0f);
+          const float tf = fminf(fminf(fminf(__builtin_fmaf(cfx, ax.x, bf.x), __builtin_fmaf(cfy, ax.y, bf.y)),
+                                       __builtin_fmaf(cfz, ax.z, bf.z)), limit);
+          if (kCount && ref[c] != kNoChild) { ++tally.boxes; ++ray_boxes; }
+          key[c] = (ref[c] != kNoChild && tn <= tf) ? tn : __builtin_inff();
+        }
+        // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
+        auto cx = [&](int a, int b) {
+          const bool sw = key[b] < key[a];
+          const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
+          const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];
+          key[a] = ka;
+          key[b] = kb;
+          ref[a] = ra;
+          ref[b] = rb;
+        };
+        cx(0, 1);
+        cx(2, 3);
+        cx(0, 2);
+        cx(1, 3);
+        cx(1, 2);
+        // the others go on the stack, farthest first
+        if (__builtin_expect(sp + 3 <= kLds4, 1)) {
+          // room for all three in LDS: write unconditionally, advance only past the ones that count (a slot that
+          // does not count is overwritten by the next write or stays above the top)
+          stack[sp * kWave] = ref[3];
+          sp += key[3] < __builtin_inff() ? 1 : 0;
+          stack[sp * kWave] = ref[2];
+          sp += key[2] < __builtin_inff() ? 1 : 0;
+          stack[sp * kWave] = ref[1];
+          sp += key[1] < __builtin_inff() ? 1 : 0;
+        } else {
+          if (key[3] < __builtin_inff()) push(ref[3]);
+          if (key[2] < __builtin_inff()) push(ref[2]);
+          if (key[1] < __builtin_inff()) push(ref[1]);
+        }
+        if (key[0] < __builtin_inff()) {
+          cur = ref[0];
+        } else {  // nothing was pushed: `below` is still the top
+          cur = below;
+          sp = sp > 0 ? sp - 1 : 0;
+        }
       } else {
-        if (key[3] < __builtin_inff()) push(ref[3]);
-        if (key[2] < __builtin_inff()) push(ref[2]);
-        if (key[1] < __builtin_inff()) push(ref[1]);
-      }
-      if (key[0] < __builtin_inff()) {
-        cur = ref[0];
-      } else {
-        cur = below;
-        sp = sp > 0 ? sp - 1 : 0;
-      }
-    }
-    const uint64_t pend_mask = __ballot(active && pend != kNoChild);
-    const uint64_t node_mask = __ballot(active && cur != kNoChild && !(cur & kLeafBit));
-    if (pend_mask != 0ull && ((uint32_t)__popcll(pend_mask) >= sc.leaf_batch || node_mask == 0ull)) {
-      if (active && pend != kNoChild) {
         // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
-        const uint32_t k = pend & ~kLeafBit;
-        pend = kNoChild;
-        const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
         if (kCount) ++tally.tris;
-        const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
+        const f3 p0 = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        const f3 e1 = mk3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+        const f3 e2 = mk3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
         const f3 h = cross(rd, e2);
         const float a = dot(e1, h);
-        // keep the first vertex's load with the other two (the compiler otherwise sinks it below the test of
-        // `a`, a second dependent memory round trip per leaf)
         const f3 sv = ro - p0;
-        asm volatile("" ::"v"(sv.x), "v"(sv.y), "v"(sv.z));
         if (!(a > -0.0000001f && a < 0.0000001f)) {
           const float f = 1.0f / a;
           const float u = f * dot(sv, h);
@@ -1366,20 +1363,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
             const float w = f * dot(rd, qv);
             if (!(w < 0.0f || u + w > 1.0f)) {
               const float t = f * dot(e2, qv);
-              if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
+              if (!(t < tmin) && (t < best_t || (t == best_t && (int)index > best_k))) {
                 best_t = t;
-                best_k = (int)k;
+                best_k = (int)index;
                 limit = scale * t * 1.001f;
               }
             }
           }
         }
+        cur = below;
+        sp = sp > 0 ? sp - 1 : 0;
       }
-    }
-    const bool done = active && pend == kNoChild && cur == kNoChild;
-    if (done) {
-      active = false;
-      pending = true;
+      if (cur == kNoChild) {
+        active = false;
+        pending = true;
+      }
     }
   }
   if (flags) atomicOr(&counters->flags, flags);

@@ -128,7 +128,6 @@ struct ptc_ctx {
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
-  uint32_t leaf_batch = 1;  // measured: batching the triangle tests (8..48 lanes) delays the hit that prunes the rest of the walk and loses 5-30 %
   int force_slow = 0;
 
   // measurement
@@ -477,7 +476,6 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   }
   d.bvh4_root = w4.root_ref;
   d.refill_lanes = ctx->refill_lanes;
-  d.leaf_batch = ctx->leaf_batch;
   d.static_eighths = ctx->static_eighths;
   d.force_slow = (uint32_t)ctx->force_slow;
   d.spill = nullptr;
@@ -707,12 +705,6 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value < 0 || value > 8) return fail(ctx, PTC_ERR_INVALID, "static_eighths must be in [0,8]");
     ctx->static_eighths = (uint32_t)value;
     ctx->scene.static_eighths = ctx->static_eighths;
-    return PTC_OK;
-  }
-  if (std::strcmp(name, "leaf_batch") == 0) {
-    if (value < 1 || value > 64) return fail(ctx, PTC_ERR_INVALID, "leaf_batch must be in [1,64]");
-    ctx->leaf_batch = (uint32_t)value;
-    ctx->scene.leaf_batch = ctx->leaf_batch;
     return PTC_OK;
   }
   if (std::strcmp(name, "refill_lanes") == 0) {

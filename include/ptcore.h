@@ -215,7 +215,6 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   flight: 1.8 ms per 1080p frame of config 5 against 2.2 ms with the defaults)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 7 = 7/8)
- *   "leaf_batch"       lanes that must hold an untested leaf before the triangle tests run (default 1)
  *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
