@@ -231,6 +231,20 @@ def test_benchmark_size_against_reference_order(pkg, big):
     assert np.isclose(got["depth"].max(), 1e6) and got["depth"].min() > 0.5
 
 
+def test_benchmark_size_soak_across_schedules(pkg, big):
+    """160 iterations (643 M rays) under four schedules -- the default 32-frame batches, eight one-frame launches of
+    1024 wavefronts, four 8-frame launches with a 7/8 static ray deal, and the two-wide kernel on twelve streams --
+    accumulate the same image bit for bit: a single differing hit anywhere would change every later random number
+    of its frame."""
+    scene, flat, depth = big
+    runs = [(), (("frames_in_flight", 8), ("batch_frames", 1), ("traverse_waves", 1024)),
+            (("frames_in_flight", 32), ("batch_frames", 8), ("traverse_waves", 2048), ("static_eighths", 7))]
+    ref = frames(pkg, scene, flat, 1920, 1080, 160, 8, params=runs[0])
+    for params in runs[1:]:
+        assert same(frames(pkg, scene, flat, 1920, 1080, 160, 8, params=params), ref), params
+    assert same(frames(pkg, scene, flat, 1920, 1080, 160, 8, variant=4, fif=12, params=(("batch_frames", 1),)), ref)
+
+
 def test_config2_size_against_reference_order(pkg):
     """Config 2: 1280x720, Cornell box + two instances of the 69,984-triangle mesh (one traversal
     launch per instance and bounce, hits carried between the object segments), 8 bounces, 9 iterations."""
