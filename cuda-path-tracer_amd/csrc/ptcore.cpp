@@ -80,6 +80,7 @@ struct ptc_ctx {
     int work_slot = 0;
     int bounces_done = 0;
     DBatchInfo bi{};            // the batch being traced / traced last
+    int capacity = 1;           // frames the slot's arrays hold
   };
   std::vector<FrameSlot> slots;
   int frames_in_flight = 64;
@@ -95,6 +96,11 @@ struct ptc_ctx {
   };
   std::vector<Pending> pending;
   uint64_t batches_issued = 0;
+  // Slots [0, big_slots) hold `batch` frames each; slots [big_slots, slots.size()) hold ONE frame: a batch of a
+  // single iteration (a viewer that presents after every iteration, the stepwise calls) goes to one of those, so
+  // that many such launches can be in flight on their own streams without the memory of full-size slots.
+  int big_slots = 0;
+  uint64_t singles_issued = 0;
   int active_slot = -1;          // slot of the frame being built by ptc_trace_begin/bounce/end
   int last_slot = 0;             // slot of the most recent finished frame
   hipEvent_t order_event = nullptr;  // last accumulate enqueued (accumulates run in iteration order)
@@ -542,11 +548,16 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   ctx->batch = B;
   ctx->staged = frames > 1;
   ctx->batches_issued = 0;
-  ctx->slots.resize((size_t)F);
+  ctx->singles_issued = 0;
+  ctx->big_slots = F;
+  const int singles = (ctx->staged && B > 1) ? 8 : 0;
+  ctx->slots.resize((size_t)(F + singles));
   if (int rc = dev_alloc(ctx, pool, &ctx->fb.color4, P)) return rc;
   if (int rc = dev_alloc(ctx, pool, &ctx->fb.nd4, P)) return rc;
-  for (int f = 0; f < F; ++f) {
+  for (int f = 0; f < F + singles; ++f) {
     auto& sl = ctx->slots[(size_t)f];
+    const int B = f < F ? ctx->batch : 1;  // this slot's capacity (shadows the batch size above)
+    sl.capacity = B;
     if (!ctx->staged) {
       sl.stream = ctx->stream;
       sl.own_stream = false;
@@ -743,7 +754,9 @@ namespace {
 // Enqueue raygen for `count` consecutive iterations on the next slot (round robin) and make it the active batch.
 int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
 {
-  const int f = (int)(ctx->batches_issued % ctx->slots.size());
+  const int single_slots = (int)ctx->slots.size() - ctx->big_slots;
+  const int f = (count == 1 && single_slots > 0) ? ctx->big_slots + (int)(ctx->singles_issued++ % (uint64_t)single_slots)
+                                                 : (int)(ctx->batches_issued++ % (uint64_t)ctx->big_slots);
   auto& sl = ctx->slots[(size_t)f];
   // the slot's previous batch has been enqueued on the same stream, so its buffers are free in stream order.
   // A main-stream consumer that still reads the framebuffers (denoise) must finish before anything is folded
@@ -772,7 +785,6 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters);
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->active_slot = f;
-  ++ctx->batches_issued;
   return PTC_OK;
 }
 
@@ -1089,7 +1101,7 @@ int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
   const size_t head = offsetof(DeviceCounters, work);  // everything but the fetch cursors
   std::vector<char> buf(sizeof(DeviceCounters));
   for (size_t f = 0; f < ctx->slots.size(); ++f)
-    for (int k = 0; k < ctx->batch; ++k) {
+    for (int k = 0; k < ctx->slots[f].capacity; ++k) {
       HIP_TRY(ctx, hipMemcpy(buf.data(), ctx->slots[f].counters + k, head, hipMemcpyDeviceToHost));
       const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
       out->rays_total += host.rays_total;
@@ -1141,7 +1153,7 @@ int ptc_reset_profile(ptc_ctx* ctx)
   std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
   const size_t off = offsetof(DeviceCounters, paths), end = offsetof(DeviceCounters, work);
   for (auto& sl : ctx->slots)
-    for (int k = 0; k < ctx->batch; ++k)
+    for (int k = 0; k < sl.capacity; ++k)
       HIP_TRY(ctx, hipMemset(reinterpret_cast<char*>(sl.counters + k) + off, 0, end - off));
   return PTC_OK;
 }
@@ -1156,7 +1168,7 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
   const size_t head = offsetof(DeviceCounters, work);
   std::vector<char> buf(sizeof(DeviceCounters));
   for (auto& sl : ctx->slots)
-    for (int k = 0; k < ctx->batch; ++k) {
+    for (int k = 0; k < sl.capacity; ++k) {
     HIP_TRY(ctx, hipMemcpy(buf.data(), sl.counters + k, head, hipMemcpyDeviceToHost));
     const DeviceCounters& host = *reinterpret_cast<const DeviceCounters*>(buf.data());
     for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {

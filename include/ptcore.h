@@ -210,9 +210,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
- *   An interactive front-end that presents or denoises after every iteration gets one-frame batches; for that
- *   pattern set "batch_frames" 1 and "frames_in_flight" 12 (twelve one-frame launches of 1024 wavefronts in
- *   flight: 1.8 ms per 1080p frame of config 5 against 2.2 ms with the defaults)
+ *   A batch of a single iteration (an interactive front-end that presents or denoises after every iteration, the
+ *   stepwise calls) runs in one of eight extra one-frame slots with streams of their own, so that viewer-style
+ *   use keeps eight frames in flight as well (config 5, 1 spp + denoise per 1080p frame: 1.6 ms)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 7 = 7/8)
  *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
