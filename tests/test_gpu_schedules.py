@@ -107,6 +107,29 @@ def test_axis_aligned_rays(pkg, orc):
         assert np.array_equal(got["color"], ref["color"]) and got["stats"]["rays_total"] == ref["rays"], variant
 
 
+def test_one_triangle_mesh(pkg, orc):
+    """A mesh of a single triangle: the reference BVH is one leaf, the four-wide tree has no node at all and the
+    walk starts at a leaf.  Two instances (one scaled and rotated) and a sphere, against the oracle."""
+    glm = pkg.glmlite
+    s = pkg.SceneDescription()
+    s.add_material("a", pkg.DiffuseMateral((0.8, 0.3, 0.3)))
+    s.add_material("m", pkg.MetalMaterial((0.9, 0.9, 0.9), 0.1))
+    tri = pkg.Mesh(np.array([[-1.5, -0.5, -1.0], [1.5, -0.5, -1.0], [0.0, 1.8, -1.4]], dtype=np.float32),
+                   np.array([0, 1, 2], dtype=np.uint32))
+    s.add_mesh("tri", tri)
+    s.add_object(tri, glm.identity(), "a")
+    s.add_object(pkg.Sphere((0, 0, 0), 0.4), glm.translate((0.2, 0.1, 0.3)), "m")
+    s.add_object(tri, glm.compose([glm.rotate(np.float32(0.9), (0.2, 1.0, 0.1)), glm.scale((0.6, 1.3, 0.8)),
+                                   glm.translate((0.3, -0.2, 0.6))]), "m")
+    s.camera = pkg.Camera(position=(0.0, 0.3, 3.0), rotation=(1.0, 0.0, 0.0, 0.0), vfov=float(np.radians(50)))
+    flat = s.build_scene()   # flat.bvh stays None: the library builds the (one-node) tree itself
+    ref = orc.render_streaming(flat, s.camera, 96, 64, 0, 5, 6)
+    for variant, fif, params in ((0, 1, ()), (3, 8, (("batch_frames", 4),)), (3, 1, ()), (4, 3, ())):
+        got = frames(pkg, s, flat, 96, 64, 5, 6, variant=variant, fif=fif, params=params)
+        assert np.array_equal(got["color"], ref["color"]) and got["stats"]["rays_total"] == ref["rays"], (variant, fif)
+    assert ref["rays"] > 96 * 64   # some paths do hit and bounce
+
+
 def test_frames_in_flight_are_folded_in_order(pkg, small_scenes):
     """Running means do not commute: 8 frames in flight must give the bits of strictly serial execution,
     also when the framebuffer is read in the middle."""
