@@ -1738,10 +1738,29 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
         ray.tmax = carried;
       }
     }
+    // 1/d by the hardware reciprocal: decides the world-box test of almost every ray without the reference's six
+    // divisions per object (below)
+    const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+    const bool winv_ok = finite_f(winv.x + winv.y + winv.z);
     for (uint32_t i = obj_begin; i < obj_end; ++i) {
       const DObject* obj = sc.objects + i;
       if (obj->type != 0u) continue;
-      if (!ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax))) continue;
+      {
+        // ray_aabb_intersection_test (intersections.cuh:87-103) decides by the sign of min(far) - max(near).  With
+        // reciprocals each slab value is within 3 ulp of the reference's quotient, so a gap beyond 2e-6 of the two
+        // extremes has the reference's sign; only a ray that grazes the box within that margin (or has a zero /
+        // non-finite direction component) takes the divisions.
+        const f3 bmin = ld3(obj->bmin), bmax = ld3(obj->bmax);
+        const f3 a0 = (bmin - ray.o) * winv, a1 = (bmax - ray.o) * winv;
+        const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+        const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+        const float gap = wf - wn, margin = 2e-6f * (fabsf(wf) + fabsf(wn)) + 1e-30f;
+        const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
+        bool pass = gap > margin;
+        const bool unsure = !box_ok || !winv_ok || !(gap > margin || gap < -margin);
+        if (__builtin_expect(unsure, 0)) pass = ray_aabb(ray.o, ray.d, bmin, bmax);
+        if (!pass) continue;
+      }
       Ray tr;
       inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
       tr.tmin = ray.tmin;
