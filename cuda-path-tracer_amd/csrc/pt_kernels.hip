@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   bool pending = false;
   uint32_t slot = 0u, cur = 0u, flags = 0u;
   int sp = 0, best_k = -1;
-  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
   bool neg_x = false, neg_y = false, neg_z = false;  // sign of 1/d per axis: which plane of a box is the near one
   float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
@@ -1145,7 +1145,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
         if (!ray_aabb(ro, rd, bmin, bmax)) {
           best_k = -1;  // the reference skips the object: the carried hit (or the miss) stands
         } else {
-          const f3 od = normalize(xform_vector(obj->inv_m, rd));
+          const f3 od = normalize(xform_vector(obj->inv_m, rd));  // inverse_transform_ray, transform.hpp:51-58
+          const f3 oo = xform_point(obj->inv_m, ro);
           float en, ef;
           if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u) {
             // a ray grazing the parent's box within rounding: redone in the reference's order by k_slow_rays
@@ -1204,13 +1205,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
           const float rlen = __builtin_amdgcn_rsqf(len2);
           scale = len2 * rlen;
           const f3 od = v * rlen;
-          oo = xform_point(obj->inv_m, ro);
+          // the origin in object space for the walk: the reference's (M^-1 (o,1)).xyz / w with the division by w
+          // (1 for an affine transform) as a reciprocal -- finalize recomputes the exact one where it decides
+          const f4 ow = mul(obj->inv_m, ro.x, ro.y, ro.z, 1.0f);
+          const f3 oo_walk = mk3(ow.x, ow.y, ow.z) * __builtin_amdgcn_rcpf(ow.w);
           inv = mk3(__builtin_amdgcn_rcpf(od.x), __builtin_amdgcn_rcpf(od.y), __builtin_amdgcn_rcpf(od.z));
           // Slab form t = fma(b, 1/d, -o/d).  Against the reference's (b - o)/d (d normalised with IEEE sqrt and
           // divide) it is off by at most ~1e-6 of |b/d| + |o/d| per axis (rsq, rcp: 1 ulp each, three roundings);
           // four times that bound (|b| <= the root box) is folded into the two origin terms so the near side
           // can only move nearer and the far side farther.
-          const f3 oi = mk3(-(oo.x * inv.x), -(oo.y * inv.y), -(oo.z * inv.z));
+          const f3 oi = mk3(-(oo_walk.x * inv.x), -(oo_walk.y * inv.y), -(oo_walk.z * inv.z));
           const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
           const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
           const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
