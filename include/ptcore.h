@@ -187,7 +187,7 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
 /* Closest-hit kernel variant (speed only; all return the same hits, bit for bit -- same box decisions, same
  * tie rule; 0-2 and 4 exist to cross-check the default on the GPU):
  *   3 (default) = persistent wavefronts whose lanes fetch the next ray as soon as their own is finished, over the
- *                 tree collapsed to four children per 128-byte node; box decisions only conservative, the
+ *                 tree collapsed to four children per 64-byte quantised node; box decisions only conservative, the
  *                 winning triangle re-checked against its parent's box with the reference's arithmetic
  *                 (sufficient: see DESIGN.md "nesting"); objects walked as sphere / mesh segments; the only
  *                 variant that traces several iterations per launch ("batch_frames")
@@ -214,7 +214,7 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   stepwise calls) runs in one of eight extra one-frame slots with streams of their own, so that viewer-style
  *   use keeps eight frames in flight as well (config 5, 1 spp + denoise per 1080p frame: 1.6 ms)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
- *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 7 = 7/8)
+ *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 3 = 3/8)
  *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
