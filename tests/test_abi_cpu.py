@@ -68,7 +68,8 @@ def test_host_bvh_builder_equals_oracle(pkg, orc, mesh_name):
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
 
 
-@pytest.mark.parametrize("mesh_name", ["grid33x17", "sphere24x48", "grid_ties", "grid257x129", "one_triangle", "thin"])
+@pytest.mark.parametrize("mesh_name", ["grid33x17", "sphere24x48", "grid_ties", "grid257x129", "one_triangle", "thin",
+                                       "benchmark_1M"])
 def test_traversal_layout_is_sound(pkg, mesh_name):
     """The default traversal walks a four-wide collapse of the reference BVH with 64-byte quantised nodes.  It only
     has to be conservative, so the invariant is containment: every quantised child box contains the exact box of the
@@ -81,6 +82,7 @@ def test_traversal_layout_is_sound(pkg, mesh_name):
         "sphere24x48": lambda: pkg.scenes.displaced_sphere_mesh(24, 48),
         "grid_ties": lambda: pkg.Mesh(*_flat_grid(17, 9)),
         "grid257x129": lambda: pkg.scenes.heightfield_mesh(257, 129, 8.0, 4.0, seed=3),
+        "benchmark_1M": lambda: list(pkg.scenes.heightfield_scene((64, 64)).mesh_map_.values())[0],  # bench.py's mesh
         "one_triangle": lambda: pkg.Mesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32),
                                          np.array([0, 1, 2], dtype=np.uint32)),
         # extents that differ by 1e6 between the axes, far from the origin: a different grid step per axis
