@@ -1,30 +1,46 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X path-tracing core.
+"""bench.py -- benchmark of the MI355X path-tracing core.
 
 Metric (BASELINE.json): Mrays/s at 1920x1080, 8 bounces, on the 1,000,000-triangle scene (config 3:
 `configs[2]`, the configuration the metric is quoted on; it fits one GPU).  One "step" = one frame =
 one sample per pixel through PathTracer::path_trace (streaming mode).  1 ray = 1 closest-hit query,
 primary rays included.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the frame's rows are dealt to the N ranks in blocks of 8 rows (round-robin: sky rows are cheap, terrain
-rows expensive, so contiguous bands would be unbalanced), one process per GPU; no data-path collective during
-tracing; the ranks' radiance is gathered to rank 0 over RCCL once, at present time, inside the timed region,
-and scattered back into frame order there.  Fixed total work -> "scaling": "strong".
+--config 3 (default)  the headline: 1M-triangle heightfield + 3 spheres, 1920x1080, 8 bounces
+--config 2            Cornell box + two instances of the 69,984-triangle mesh, 1280x720, 8 bounces (N=1)
+--config 5            config 3's scene, 1 spp + the A-Trous denoiser after EVERY frame, presented every frame
+                      (interactive mode; metric ms per frame; roofline of k_denoise) (N=1)
+
+N > 1 (config 3): the frame's rows are dealt to the N ranks in blocks of 8 rows (round-robin: sky rows are
+cheap, terrain rows expensive, so contiguous bands would be unbalanced), one process per GPU; no data-path
+collective during tracing; the ranks' radiance is gathered to rank 0 over RCCL once, at present time, inside the
+timed region, and scattered back into frame order there.  Fixed total work -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 with the contract fields plus:
-  roofline      dominant kernel = the closest-hit (trace) kernel; achieved = algorithmic bytes of all its
-                launches in the timed region / their summed duration (HIP events on the kernel's stream);
-                launches of several frames in flight overlap, so achieved_chip (bytes / wall time) is given too.
-                Algorithmic bytes per launch = n*52 + box_tests*32 + tri_tests*48 (the
-                reference's node / triangle sizes), with the test counts taken from an instrumented, untimed
-                re-run of the same frames; achieved_own_layout prices a box test at the 16 bytes this
-                implementation's 64-byte four-box nodes cost.  Most of these bytes are served by L2 / Infinity
-                Cache (roofline.traffic), so achieved can exceed the HBM peak.
-  cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU path) timed on this
-                box's cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      dominant kernel = the closest-hit (trace) kernel k_traverse4.
+                achieved = SURVEY 8(d)'s ALGORITHMIC bytes of all its launches in the timed region / their summed
+                duration (HIP events on the kernel's stream, recorded inside libptcore around every launch).
+                Algorithmic bytes of a launch = rays*52 + node_visits*32 + tri_tests*48 (32 B per BVH node visited,
+                12 B indices + 36 B vertices per triangle test, 32 B ray read + 20 B compact hit written per ray:
+                layout-independent minimums taken from the reference's node / triangle sizes), with the counts from
+                an instrumented, untimed re-run of the same frames.  `requested` prices what THIS layout asks the
+                memory system for (64-byte four-child node records, 48-byte triangle records).  `traffic` = HBM-side
+                bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json), given only when
+                that record was taken on the same launch shape (frames per launch), else null.  The kernel is not
+                HBM-bound -- its working set lives in L2 / Infinity Cache -- so `valu` carries the roofline that
+                does bind it: VALU issue (busy %, lanes per instruction, instructions per ray; SQ counter passes,
+                profiles/pmc_sq.json).
+  parity        GPU iteration 0 of the benchmark scene against the CPU oracle's frame (the one rendered for
+                cpu_baseline): mse, bit_exact, live counts and ray count equal.
+  steady_state  the same workload with 32 frames per launch and 256 steps (the tuned schedule; the timed region
+                above runs exactly --steps frames, which the driver sets to 20).
+  latency       ms per frame when frames are strictly serial (one frame in flight) and in the viewer pattern
+                (present after every iteration; eight one-frame slots).
+  cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU path) timed on this box's cores on
+                a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -44,53 +60,97 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BLOCK_ROWS = 8         # multi-GPU: rows are dealt to the ranks in blocks of this many
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=128)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5))
+    ap.add_argument("--width", type=int, default=0, help="0 = the configuration's resolution")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--grid", type=str, default="1001x501", help="heightfield vertex grid (1001x501 = 1,000,000 triangles)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = streams x the batch size")
     ap.add_argument("--batch-frames", type=int, default=0,
-                    help="frames traced per launch; 0 = up to 32, chosen so that the timed steps split evenly over the streams")
+                    help="frames traced per launch; 0 = 32, or an even split of --steps over the streams when --steps is "
+                         "smaller than one round of full batches")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--no-events", action="store_true", help="do not time the trace kernel with HIP events (diagnostic)")
-    ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="resolution of the CPU-oracle sample frame")
+    ap.add_argument("--cpu-sample", type=str, default="", help="resolution of the CPU-oracle sample frame (default: the full frame)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (the GPU box's CPU share for one GPU is 16)")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+def pmc_record(name, frames_per_launch):
+    """profiles/<name>: counter figures of the dominant kernel from separate rocprofv3 --pmc passes."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    rec["matches_this_run"] = rec.get("frames_per_launch") == frames_per_launch
+    return rec
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    rehearse = args.rehearse_on_one_gpu
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if rehearse:
-            dist.init_process_group(backend="gloo")
+
+def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
+    """SURVEY 8(d) pricing of the closest-hit launches of the timed region."""
+    scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
+    rays = sum(paths_timed)
+    nodes = sum(scale[b] * counted["node_visits"][b] for b in range(MB))
+    boxes = sum(scale[b] * counted["box_tests"][b] for b in range(MB))
+    tris = sum(scale[b] * counted["tri_tests"][b] for b in range(MB))
+    alg_bytes = rays * 52 + nodes * 32 + tris * 48          # SURVEY 8(d): 32 B per node visit
+    req_bytes = rays * 52 + nodes * 64 + tris * 48          # this layout: 64-byte node records
+    trace_ms = sum(prof["trace_ms"])
+    launches = sum(prof["trace_launches"])
+    achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+    traffic_rec = pmc_record("pmc_traffic.json", frames_per_launch)
+    traffic = note = None
+    if traffic_rec is not None:
+        if traffic_rec["matches_this_run"]:
+            traffic = traffic_rec.get("trace_kernel_hbm_bytes_per_launch")
+            note = "profiles/pmc_traffic.json (%s)" % traffic_rec.get("source", "separate --pmc passes")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    coll_dev = "cpu" if rehearse else "cuda"
+            note = ("null: profiles/pmc_traffic.json was measured on %s-frame launches (%.3g GB per launch), this run used %d"
+                    % (traffic_rec.get("frames_per_launch"), (traffic_rec.get("trace_kernel_hbm_bytes_per_launch") or 0) / 1e9,
+                       frames_per_launch))
+    roof = {
+        "bound": "hbm",
+        "kernel": "k_traverse4 (closest hit: persistent wavefronts over the 4-wide quantised BVH, %d frames per launch)" % frames_per_launch,
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic, "traffic_note": note,
+        "pricing": "SURVEY 8(d): rays*52 + node_visits*32 + tri_tests*48 bytes",
+        "launches": launches, "avg_launch_us": round(trace_ms * 1e3 / max(launches, 1), 2),
+        "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
+        "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
+        "requested_bytes_per_launch": round(req_bytes / max(launches, 1)),
+        "achieved_requested": round(req_bytes / (trace_ms * 1e-3) / 1e9, 2) if trace_ms > 0 else 0.0,
+        "frac_requested": round(req_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if trace_ms > 0 else 0.0,
+        "concurrent_launches": round(trace_ms * 1e-3 / elapsed, 3),
+        "node_visits_per_ray": round(nodes / max(rays, 1), 2),
+        "box_tests_per_ray": round(boxes / max(rays, 1), 2),
+        "tri_tests_per_ray": round(tris / max(rays, 1), 2),
+        "note": "the kernel's working set (27 MB of nodes + 48 MB of triangles + path state of the batch) is served "
+                "by L2 / Infinity Cache; it is bound by VALU issue at about half lane utilisation, see valu",
+    }
+    sq = pmc_record("pmc_sq.json", frames_per_launch)
+    if sq is not None:
+        roof["valu"] = {k: sq.get(k) for k in ("valu_busy_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
+                                                "l2_hit_frac", "frames_per_launch", "source")}
+    return roof
 
-    pkg = graft.load_package()
-    W, H, MB = args.width, args.height, args.max_bounces
+
+def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
+    coll_dev = "cpu" if rehearse else "cuda"
+    W, H, MB = args.width or 1920, args.height or 1080, args.max_bounces
     nx, nz = (int(v) for v in args.grid.split("x"))
     scene = pkg.scenes.heightfield_scene((W, H), nx=nx, nz=nz)
     flat = scene.build_scene()
@@ -98,36 +158,37 @@ def main():
     t0 = time.perf_counter()
     flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)
     bvh_build_s = time.perf_counter() - t0
-
-    # rows in blocks of BLOCK_ROWS dealt round-robin over the ranks (cuda-path-tracer_amd/bands.py)
-    BLOCK_ROWS = 8
     rank_rows = pkg.bands.interleaved_rows(H, world, BLOCK_ROWS)
 
-    pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
     # Schedule: `batch` consecutive frames share every launch (the latency tail of a bounce -- a few long rays --
     # and the drain of the persistent wavefronts are paid once per batch) and `streams` batches are in flight so
-    # that the small kernels and the tail of one overlap the bulk of another.  A rank that owns 1/N of the rows
-    # has 1/N of the rays per launch and, from N = 4 on, keeps 4 smaller batches in flight (measured on 1/2, 1/4 and
-    # 1/8 shares of the rows on one GPU).  Results do not depend on any of it
-    # (tests/test_gpu_schedules.py).
+    # that the small kernels and the tail of one overlap the bulk of another.  32 frames per launch is the tuned
+    # value; a timed region shorter than one round of full batches (the driver's --steps 20) is split evenly over
+    # the streams instead, and the tuned schedule is reported beside it (steady_state).  Results do not depend on
+    # any of it (tests/test_gpu_schedules.py).
     streams = args.streams or (2 if world <= 2 else 4)
     if args.batch_frames:
         batch = args.batch_frames
+    elif args.steps >= streams * 32:
+        batch = 32
     else:
-        rounds = max(1, -(-args.steps // (streams * 32)))
-        batch = max(1, min(32, -(-args.steps // (streams * rounds))))
-    args.batch_frames = batch
-    args.frames_in_flight = args.frames_in_flight or streams * batch
-    pt.set_param("frames_in_flight", args.frames_in_flight)
-    pt.set_param("batch_frames", batch)
-    # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU (a second launch's
-    # wavefronts move in as the first one's drain); half of that for the smaller launches of a rank among 4 or 8
-    pt.set_param("traverse_waves", 5120 if world <= 2 else 2560)
-    pt.create_buffers((W, H), flat)
-    pt.set_stream(torch.cuda.current_stream().cuda_stream)
-    if world > 1:
-        pt.set_interleave(rank, world, BLOCK_ROWS)
-    pt.max_iterations = 1 << 30
+        batch = max(1, min(32, -(-args.steps // streams)))
+
+    def make_tracer(batch_frames, n_streams):
+        pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+        pt.set_param("frames_in_flight", n_streams * batch_frames)
+        pt.set_param("batch_frames", batch_frames)
+        # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU; half of that for
+        # the smaller launches of a rank among 4 or 8
+        pt.set_param("traverse_waves", 5120 if world <= 2 else 2560)
+        pt.create_buffers((W, H), flat)
+        pt.set_stream(torch.cuda.current_stream().cuda_stream)
+        if world > 1:
+            pt.set_interleave(rank, world, BLOCK_ROWS)
+        pt.max_iterations = 1 << 30
+        return pt
+
+    pt = make_tracer(batch, streams)
     # gather needs equal sizes on every rank: pad each rank's rows to the largest share
     max_rows = max(len(rr) for rr in rank_rows)
     band_color = torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda")
@@ -137,9 +198,9 @@ def main():
         frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
         row_index = [torch.tensor(rank_rows[r], dtype=torch.long, device="cuda") for r in range(world)]
 
-    def present():
+    def present(tracer):
         """gather of per-rank radiance at present time (the only inter-GPU traffic) + back into frame order"""
-        pt.download_to_device("color", band_color.data_ptr())
+        tracer.download_to_device("color", band_color.data_ptr())
         if world > 1:
             if rehearse:
                 parts = [torch.empty(g.shape, dtype=g.dtype) for g in gathered] if rank == 0 else None
@@ -158,84 +219,98 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pt.path_trace(scene.camera)
-    present()
-    fence()
-    pt.reset_profile()
-    pt.set_profiling(time_trace_kernel=not args.no_events, count_tests=False)
-    rays0 = pt.stats()["rays_total"]
-    first_iter = pt.iteration()
+    def timed(tracer, steps, warmup):
+        for _ in range(warmup):
+            tracer.path_trace(scene.camera)
+        present(tracer)
+        fence()
+        tracer.reset_profile()
+        tracer.set_profiling(time_trace_kernel=not args.no_events, count_tests=False)
+        rays0 = tracer.stats()["rays_total"]
+        first_iter = tracer.iteration()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tracer.path_trace(scene.camera)
+        present(tracer)
+        fence()
+        elapsed = time.perf_counter() - t0
+        rays = tracer.stats()["rays_total"] - rays0
+        prof = tracer.profile()
+        tracer.set_profiling(False, False)
+        if world > 1:   # max over ranks of the elapsed time, sum of rays
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            r = torch.tensor([rays], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            rays = int(r.item())
+        return elapsed, rays, prof, first_iter
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pt.path_trace(scene.camera)
-    present()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def count_tests(tracer, first_iter, steps):
+        """instrumented, untimed re-run of the same frames: node visits / box tests / triangle tests per bounce"""
+        tracer.set_profiling(time_trace_kernel=False, count_tests=True)
+        tracer.reset_profile()
+        tracer.set_iteration(first_iter)
+        for _ in range(min(steps, 4)):
+            tracer.path_trace(scene.camera)
+        counted = tracer.profile()
+        tracer.set_profiling(False, False)
+        return counted
 
-    rays = pt.stats()["rays_total"] - rays0
-    prof = pt.profile()
+    elapsed, rays, prof, first_iter = timed(pt, args.steps, args.warmup)
     last_live = pt.stats()["last_live"]
+    counted = count_tests(pt, first_iter, args.steps)
+    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch)
+    slow_rays = sum(prof["slow_rays"])
 
-    # max over ranks of the elapsed time, sum of rays
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays = int(r.item())
+    # the tuned schedule on the same workload (only when the timed region above was too short to show it)
+    steady = None
+    if not args.no_extras and (batch != 32 or args.steps < 256):
+        if batch != 32:
+            pt.close()
+            pt = make_tracer(32, streams)
+        s_el, s_rays, s_prof, s_first = timed(pt, 256, 64)
+        s_counted = count_tests(pt, s_first, 4)
+        s_roof = trace_roofline(s_prof, s_counted, list(s_prof["paths"]), MB, s_el, 32)
+        steady = {"value": round(s_rays / s_el / 1e6, 3), "unit": "Mrays/s", "steps": 256, "warmup": 64, "frames_per_launch": 32,
+                  "frames_in_flight": streams * 32, "ms_per_step": round(s_el / 256 * 1e3, 4),
+                  "roofline_frac": s_roof["frac"], "roofline_achieved": s_roof["achieved"],
+                  "avg_launch_us": s_roof["avg_launch_us"], "traffic": s_roof["traffic"],
+                  "frac_requested": s_roof["frac_requested"]}
+    pt.close()
 
-    # instrumented, untimed re-run of the same frames: BVH box / triangle test counts per bounce
-    pt.set_profiling(time_trace_kernel=False, count_tests=True)
-    paths_timed = list(prof["paths"])
-    pt.reset_profile()
-    pt.set_iteration(first_iter)
-    count_steps = min(args.steps, 4)
-    for _ in range(count_steps):
-        pt.path_trace(scene.camera)
-    counted = pt.profile()
-    pt.set_profiling(False, False)
+    # single-frame latency: strictly serial frames, and the viewer pattern (app.cpp:141-170 presents every frame)
+    latency = None
+    if not args.no_extras and world == 1:
+        latency = {}
+        rgba = torch.empty((H, W), dtype=torch.int32, device="cuda")
+        for key, fif, every in (("serial_frame_ms", 1, False), ("present_every_frame_ms", 4, True)):
+            lp = pkg.PathTracer(device=local_rank, max_bounces=MB)
+            lp.set_param("frames_in_flight", fif)
+            lp.set_param("batch_frames", min(fif, 2))
+            lp.create_buffers((W, H), flat)
+            lp.set_stream(torch.cuda.current_stream().cuda_stream)
+            lp.max_iterations = 1 << 30
+            for _ in range(8):
+                lp.path_trace(scene.camera)
+                if every:
+                    lp.send_to_preview(rgba.data_ptr())
+            lp.synchronize()
+            t0 = time.perf_counter()
+            n = 32
+            for _ in range(n):
+                lp.path_trace(scene.camera)
+                if every:
+                    lp.send_to_preview(rgba.data_ptr())
+            lp.synchronize()
+            latency[key] = round((time.perf_counter() - t0) / n * 1e3, 4)
+            lp.close()
 
-    # roofline of the dominant kernel (trace): algorithmic bytes / summed launch duration
-    scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
-    alg_bytes = sum(paths_timed[b] * 52 + scale[b] * (counted["box_tests"][b] * 32 + counted["tri_tests"][b] * 48)
-                    for b in range(MB))
-    # the same sum with what THIS implementation fetches per test (16 B per box: four boxes in a 64-byte node)
-    own_bytes = sum(paths_timed[b] * 52 + scale[b] * (counted["box_tests"][b] * 16 + counted["tri_tests"][b] * 48)
-                    for b in range(MB))
-    trace_ms = sum(prof["trace_ms"])
-    launches = sum(prof["trace_launches"])
-    achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_file):
-        try:
-            traffic = json.load(open(pmc_file)).get("trace_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # Frames in flight overlap launches of this kernel on several streams: `achieved` is what ONE launch gets
-    # while sharing the chip (bytes of a launch / its own duration); achieved_chip is all launches' bytes over
-    # the wall time of the timed region.
-    achieved_chip = alg_bytes / elapsed / 1e9
-    roofline = {
-        "bound": "hbm", "kernel": "k_traverse4 (closest hit: persistent wavefronts over the 4-wide BVH, %d frames per launch)" % args.batch_frames, "achieved": round(achieved, 2),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "launches": launches, "avg_launch_us": round(trace_ms * 1e3 / max(launches, 1), 2),
-        "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
-        "concurrent_launches": round(trace_ms * 1e-3 / elapsed, 3),
-        "achieved_chip": round(achieved_chip, 2), "frac_chip": round(achieved_chip / HBM_PEAK_GBS, 5),
-        "achieved_own_layout": round(own_bytes / (trace_ms * 1e-3) / 1e9, 2) if trace_ms > 0 else 0.0,
-        "box_tests_per_ray": round(sum(counted["box_tests"]) / max(sum(counted["paths"]), 1), 2),
-        "tri_tests_per_ray": round(sum(counted["tri_tests"]) / max(sum(counted["paths"]), 1), 2),
-    }
-
-    cpu_baseline = None
+    cpu_baseline = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         orc = graft.load_oracle()
-        cw, ch = (int(v) for v in args.cpu_sample.split("x"))
+        cw, ch = (int(v) for v in args.cpu_sample.split("x")) if args.cpu_sample else (W, H)
         sh = orc.SceneHandle(flat)
         cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
         t0 = time.perf_counter()
@@ -245,25 +320,214 @@ def main():
                         "sample": f"1 frame of the same scene (same {len(flat.indices) // 3}-triangle BVH, {MB} bounces) at "
                                   f"{cw}x{ch}: {ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so (CPU restatement; "
                                   "the reference has no CPU path)"}
+        # the production schedule's iteration 0 of the same frame against that oracle frame
+        with pkg.PathTracer(device=local_rank, max_bounces=MB) as cp:
+            cp.set_param("frames_in_flight", 2)
+            cp.create_buffers((cw, ch), flat)
+            cp.max_iterations = 1
+            cp.path_trace(scene.camera)
+            got = {k: cp.download(k) for k in ("color", "normal", "depth")}
+            st = cp.stats()
+        d = got["color"].astype(np.float64) - ref["color"].astype(np.float64)
+        parity = {"against": "oracle frame of cpu_baseline (iteration 0, %dx%d, default schedule)" % (cw, ch),
+                  "mse": float(np.mean(np.sum(d * d, axis=-1))),
+                  "bit_exact": bool(all(np.array_equal(got[k], ref[k]) for k in ("color", "normal", "depth"))),
+                  "live_equal": bool(st["last_live"] == [int(v) for v in ref["live"][-1][:MB]]),
+                  "rays_equal": bool(st["rays_total"] == ref["rays"]), "tolerance_mse": 1e-4}
 
-    if rank == 0:
-        value = rays / elapsed / 1e6
-        line = {
-            "metric": "Mrays/s at 1920\u00d71080, 8 bounces", "value": round(value, 3), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config 3: procedural {len(flat.indices) // 3}-triangle heightfield + 3 spheres, "
-                                   f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
-                       "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
-                       "resolution": [W, H], "max_bounces": MB, "frames_in_flight": args.frames_in_flight, "frames_per_launch": args.batch_frames, "rays_per_step": round(rays / args.steps),
-                       "live_per_bounce_last_frame_rank0": last_live, "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks",
-                       "bvh_build_s": round(bvh_build_s, 3)},
-            "roofline": roofline,
-            "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(line), flush=True)
+    if rank != 0:
+        return None
+    value = rays / elapsed / 1e6
+    return {
+        "metric": "Mrays/s at 1920×1080, 8 bounces", "value": round(value, 3), "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config 3: procedural {len(flat.indices) // 3}-triangle heightfield + 3 spheres, "
+                               f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
+                   "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
+                   "resolution": [W, H], "max_bounces": MB, "frames_in_flight": streams * batch,
+                   "frames_per_launch": batch,
+                   "schedule_note": ("tuned schedule (32 frames per launch)" if batch == 32 else
+                                     f"--steps {args.steps} is less than one round of full batches: {streams} launches of {batch} "
+                                     "frames; the tuned 32-frame schedule is reported under steady_state"),
+                   "rays_per_step": round(rays / args.steps),
+                   "live_per_bounce_last_frame_rank0": last_live, "exact_redo_rays": slow_rays,
+                   "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks",
+                   "bvh_build_s": round(bvh_build_s, 3)},
+        "roofline": roofline,
+        "parity": parity,
+        "steady_state": steady,
+        "latency": latency,
+        "cpu_baseline": cpu_baseline,
+    }
+
+
+def run_config2(args, pkg, torch, local_rank):
+    """Config 2: Cornell box + two instances of the 69,984-triangle stand-in mesh, 1280x720."""
+    W, H, MB = args.width or 1280, args.height or 720, args.max_bounces
+    scene = pkg.scenes.cornell_bunny((W, H))
+    flat = scene.build_scene()
+    mesh = list(scene.mesh_map_.values())[0]
+    flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)
+    batch = args.batch_frames or 32
+    streams = args.streams or 2
+    pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+    pt.set_param("frames_in_flight", streams * batch)
+    pt.set_param("batch_frames", batch)
+    pt.create_buffers((W, H), flat)
+    pt.set_stream(torch.cuda.current_stream().cuda_stream)
+    pt.max_iterations = 1 << 30
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    for _ in range(args.warmup):
+        pt.path_trace(scene.camera)
+    pt.download_to_device("color", out.data_ptr())
+    torch.cuda.synchronize()
+    pt.reset_profile()
+    pt.set_profiling(time_trace_kernel=not args.no_events, count_tests=False)
+    rays0 = pt.stats()["rays_total"]
+    first_iter = pt.iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pt.path_trace(scene.camera)
+    pt.download_to_device("color", out.data_ptr())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rays = pt.stats()["rays_total"] - rays0
+    prof = pt.profile()
+    last_live = pt.stats()["last_live"]
+    pt.set_profiling(False, True)
+    pt.reset_profile()
+    pt.set_iteration(first_iter)
+    for _ in range(min(args.steps, 4)):
+        pt.path_trace(scene.camera)
+    counted = pt.profile()
+    pt.set_profiling(False, False)
+    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch)
+    roofline["kernel"] += "; one launch per mesh instance and bounce"
     pt.close()
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        orc = graft.load_oracle()
+        cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
+        t0 = time.perf_counter()
+        ref = orc.render_streaming(flat, scene.camera, W, H, 0, 2, MB, nthreads=cores)
+        dt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(ref["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                        "sample": f"2 frames of the same scene at {W}x{H}: {ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so"}
+    return {
+        "metric": "Mrays/s at 1280×720, 8 bounces (config 2)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config 2: Cornell box (5 wall spheres + 3 balls) + two instances of a {len(flat.indices) // 3}-triangle "
+                               f"displaced sphere (stand-in for bunny.obj, an LFS pointer in the reference), {W}x{H}, {MB} bounces",
+                   "triangles": len(flat.indices) // 3, "instances": 2, "bvh_depth": int(bvh_depth), "resolution": [W, H],
+                   "max_bounces": MB, "frames_in_flight": streams * batch, "frames_per_launch": batch,
+                   "rays_per_step": round(rays / args.steps), "live_per_bounce_last_frame_rank0": last_live},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+
+
+def run_config5(args, pkg, torch, local_rank):
+    """Config 5: 1 spp interactive mode + Edge-Avoiding A-Trous denoise after every frame, 1920x1080."""
+    W, H, MB = args.width or 1920, args.height or 1080, args.max_bounces
+    nx, nz = (int(v) for v in args.grid.split("x"))
+    scene = pkg.scenes.heightfield_scene((W, H), nx=nx, nz=nz)
+    flat = scene.build_scene()
+    flat.bvh, bvh_depth = pkg.bvh_from_mesh(list(scene.mesh_map_.values())[0])
+    P = W * H
+    rgba = torch.empty((H, W), dtype=torch.int32, device="cuda")
+
+    def loop(denoise, steps, warmup, events):
+        pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+        pt.set_param("frames_in_flight", 4)   # a present after every iteration leaves no room for more
+        pt.set_param("batch_frames", 2)
+        pt.create_buffers((W, H), flat)
+        pt.set_stream(torch.cuda.current_stream().cuda_stream)
+        pt.max_iterations = 1 << 30
+        for _ in range(warmup):
+            pt.restart()                      # a moving camera: every frame starts a new image (app.cpp:112,130)
+            pt.path_trace(scene.camera)
+            if denoise:
+                pt.denoise()
+            pt.send_to_preview(rgba.data_ptr())
+        torch.cuda.synchronize()
+        pt.reset_profile()
+        pt.set_profiling(time_trace_kernel=events, count_tests=False)
+        rays0 = pt.stats()["rays_total"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pt.restart()
+            pt.path_trace(scene.camera)
+            if denoise:
+                pt.denoise()
+            pt.send_to_preview(rgba.data_ptr())
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rays = pt.stats()["rays_total"] - rays0
+        prof = pt.profile()
+        pt.close()
+        return el, rays, prof
+
+    el, rays, prof = loop(True, args.steps, args.warmup, not args.no_events)
+    el_nd, _, _ = loop(False, args.steps, args.warmup, False)
+    passes = max(prof["denoise_passes"], 1)
+    den_ms_pass = prof["denoise_ms"] / passes
+    # HBM-side algorithmic bytes of one pass: colour 16 + normal/depth 16 + position 16 read, 16 written per pixel
+    pass_bytes = 64 * P
+    achieved = pass_bytes / (den_ms_pass * 1e-3) / 1e9 if den_ms_pass > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_denoise (A-Trous pass, 5x5 taps at stride 1/2/4/8)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "pricing": "(48 B read + 16 B written) per pixel and pass", "launches": prof["denoise_passes"],
+                "avg_launch_us": round(den_ms_pass * 1e3, 2), "alg_bytes_per_launch": pass_bytes}
+    return {
+        "metric": "ms per frame: 1 spp + A-Trous denoise + present at 1920×1080, 8 bounces (config 5)",
+        "value": round(el / args.steps * 1e3, 4), "unit": "ms/frame", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config 5: config 3's scene ({len(flat.indices) // 3} triangles), {W}x{H}, {MB} bounces, every frame = "
+                               "restart + 1 spp + 4-pass A-Trous (filter_size 10, .45/.30/.25) + present; G-buffer in HBM",
+                   "resolution": [W, H], "max_bounces": MB, "rays_per_step": round(rays / args.steps),
+                   "ms_per_frame_without_denoise": round(el_nd / args.steps * 1e3, 4),
+                   "denoise_ms_per_frame_kernel_time": round(prof["denoise_ms"] / args.steps, 4),
+                   "denoise_ms_per_pass": round(den_ms_pass, 4), "mrays_per_s": round(rays / el / 1e6, 1)},
+        "roofline": roofline, "cpu_baseline": None,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.config != 3:
+        raise SystemExit("--config 2 and 5 are single-GPU workloads")
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    if args.config == 3:
+        line = run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse)
+    elif args.config == 2:
+        line = run_config2(args, pkg, torch, local_rank)
+    else:
+        line = run_config5(args, pkg, torch, local_rank)
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -73,11 +73,13 @@ struct DScene {
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
   const float4* leaf_parent;       // 2 float4 per triangle
   const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
+  uint32_t* slow_stack;            // global traversal stack of the launch's exact redo (redo_slow_rays), [kStackDepth][kWave]
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
   uint32_t spill_cap;              // entries per thread in `spill`
+  uint32_t lds_cap;                // entries per lane kept in LDS before `spill` (kLds4; fewer only in tests)
   uint32_t bvh4_root;
-  uint32_t force_slow;             // test hook: hand EVERY ray to k_slow_rays
+  uint32_t force_slow;             // test hook: hand EVERY ray to the exact redo (redo_slow_rays)
   uint32_t static_eighths;         // persistent traversal: share (x/8) of each image region dealt without atomics
   uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle
   float root_min[3];               // box of the root (tested before descending, like any inner node)
@@ -146,7 +148,8 @@ struct DFrame {
 struct DeviceCounters {
   uint32_t live[kMaxBounces + 1];  // live paths entering bounce b of the current frame
   uint32_t flags;
-  uint32_t slow_count;             // rays handed to k_slow_rays by the running traversal launch
+  uint32_t slow_count;             // rays set aside for the exact redo by the running traversal launch
+  uint32_t waves_done;             // wavefronts of the running traversal launch that have signed off
   unsigned long long rays_total;
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
@@ -154,7 +157,8 @@ struct DeviceCounters {
   uint32_t max_box_tests[kMaxBounces];        // longest single traversal (box tests of one ray), instrumented runs
   uint32_t max_ray_cycles[kMaxBounces];       // longest single traversal in shader clocks (s_memtime), instrumented runs
   uint32_t max_wave_cycles[kMaxBounces];      // longest-lived persistent wavefront, instrumented runs
-  unsigned long long slow_rays[kMaxBounces];  // rays redone by k_slow_rays
+  unsigned long long slow_rays[kMaxBounces];  // rays redone exactly (redo_slow_rays)
+  unsigned long long node_visits[kMaxBounces];  // BVH node records fetched by the closest-hit kernels, instrumented runs
   // ray-fetch cursors of the persistent traversal launches, one per image region, each on its own 128-byte
   // line (cursors sharing a line serialise in L2: measured ~30 atomics/us for the whole line)
   uint32_t work[kWorkSlots][8][32];
@@ -184,19 +188,18 @@ void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DB
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests, int variant);
-// variant 2 (default): per bounce, the objects are walked in the reference's order as a sequence of segments:
+// variant 3 (default): per bounce, the objects are walked in the reference's order as a sequence of segments:
 //   launch_spheres  objects [obj_begin, obj_end), all spheres; carries the closest hit so far in the hit record
 //                   (first: nothing to read; last: also emits the per-chunk live counts for the compaction scan)
-//   launch_traverse one mesh object: persistent wavefronts, each lane fetches the next ray when its own is done
+//   launch_traverse one mesh object: persistent wavefronts, each lane fetches the next ray when its own is done;
+//                   rays it sets aside (degenerate direction, winner grazing its parent box) are redone exactly by
+//                   the last wavefront of the same launch
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
                     DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
                     DeviceCounters* counters, const DBatchInfo& bi);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                      uint32_t* slow_list, const DBatchInfo& bi);
-// rays with a degenerate direction that the persistent kernels set aside: reference-order traversal
-void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                      const uint32_t* slow_list, DeviceCounters* counters, int bounce);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters, const DBatchInfo& bi);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

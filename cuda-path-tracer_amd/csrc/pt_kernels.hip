@@ -47,7 +47,7 @@ __device__ __forceinline__ f3 ray_at(const Ray& r, float t) { return r.o + r.d *
 
 // per-lane test counters of the instrumented kernel variant
 struct Tally {
-  uint32_t boxes = 0u, tris = 0u;
+  uint32_t boxes = 0u, tris = 0u, nodes = 0u;  // ray/box tests, ray/triangle tests, node records fetched
 };
 
 struct Hit {
@@ -57,6 +57,25 @@ struct Hit {
   uint32_t mat;
   uint32_t side;  // 0 front, 1 back
 };
+
+// wavefront totals of the instrumented kernel variants -> the counter block (one atomic each)
+__device__ __forceinline__ void flush_tally(const Tally& tally, DeviceCounters* counters, int bounce, bool per_ray_max)
+{
+  uint32_t b = tally.boxes, t = tally.tris, nd = tally.nodes, mx = tally.boxes;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    b += __shfl_down(b, off, 64);
+    t += __shfl_down(t, off, 64);
+    nd += __shfl_down(nd, off, 64);
+    mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
+    atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
+    atomicAdd(&counters->node_visits[bounce], (unsigned long long)nd);
+    if (per_ray_max) atomicMax(&counters->max_box_tests[bounce], mx);  // one lane = one ray in those kernels
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // intersection tests (reference intersections.cuh)
@@ -163,7 +182,7 @@ __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObjec
         hit = true;
         ray.tmax = rec.t;
       }
-    } else if ((kCount ? (void)++tally.boxes : (void)0), ray_aabb(oo, od, xyz(n0), xyz(n1))) {
+    } else if ((kCount ? (void)(++tally.boxes, ++tally.nodes) : (void)0), ray_aabb(oo, od, xyz(n0), xyz(n1))) {
       if (sp + 2 > stack_cap) {
         flags |= kFlagStackOverflow;
       } else {
@@ -225,7 +244,7 @@ __device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, u
 //     so far or behind the ray origin (such triangles cannot be accepted), and leaves whose own box is
 //     missed with a margin are skipped (the reference tests no leaf boxes; those tests would fail);
 //   * children are visited nearest first; one LDS stack slot per level.
-constexpr int kWideStack = 32;
+constexpr int kWideStack = kStackDepth;  // one entry per level of the two-wide tree (ptc_upload_scene checks the depth)
 
 __device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < __builtin_inff(); }
 
@@ -334,7 +353,7 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
     const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
     const f3 lmin = mk3(w0.x, w0.y, w0.z), lmax = mk3(w0.w, w1.x, w1.y);
     const f3 rmin = mk3(w1.z, w1.w, w2.x), rmax = mk3(w2.y, w2.z, w2.w);
-    if (kCount) tally.boxes += 2u;
+    if (kCount) { tally.boxes += 2u; ++tally.nodes; }
     // Both children through the same code.  An inner child's decision must equal the reference's: the
     // shortcut decides unless the slab extremes are closer than its rounding error (then: exact test).
     // A leaf child's box is not part of the reference's decision: its triangle is skipped only when the
@@ -606,22 +625,7 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
   }
   const uint64_t live = __ballot(hit);
   if (threadIdx.x == 0u) chunk_counts[blockIdx.x] = (uint32_t)__popcll(live);
-  if (kCount) {
-    uint32_t b = tally.boxes, t = tally.tris;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      b += __shfl_down(b, off, 64);
-      t += __shfl_down(t, off, 64);
-    }
-    uint32_t mx = tally.boxes;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
-    if (threadIdx.x == 0u) {
-      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
-      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
-      atomicMax(&counters->max_box_tests[bounce], mx);
-    }
-  }
+  if (kCount) flush_tally(tally, counters, bounce, true);
 }
 
 // The same kernel over the wide layout (default).  Chunks are dealt to workgroups so that workgroups that
@@ -656,102 +660,21 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
   }
   const uint64_t live = __ballot(hit);
   if (threadIdx.x == 0u) chunk_counts[chunk] = (uint32_t)__popcll(live);
-  if (kCount) {
-    uint32_t b = tally.boxes, t = tally.tris;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      b += __shfl_down(b, off, 64);
-      t += __shfl_down(t, off, 64);
-    }
-    uint32_t mx = tally.boxes;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
-    if (threadIdx.x == 0u) {
-      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
-      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
-      atomicMax(&counters->max_box_tests[bounce], mx);
-    }
-  }
+  if (kCount) flush_tally(tally, counters, bounce, true);
 }
 
 // ------------------------------------------------------------------------------------------------
-// variant 2: persistent traversal with per-lane ray fetch
+// persistent traversal: ray hand-out
 // ------------------------------------------------------------------------------------------------
-// Traversal lengths differ by an order of magnitude between neighbouring rays (a ray that grazes the
-// terrain tests hundreds of boxes, its neighbour a few dozen), so "one wavefront = 64 fixed rays" leaves
-// most lanes idle most of the time (measured: 21 % of lanes active per VALU instruction).  Here a wavefront
-// lives for the whole launch and every lane that finishes its ray takes the next unprocessed one from a
-// device-side cursor.  Results are written per slot, so the order in which rays are processed is
-// irrelevant to the output.  One launch handles ONE mesh object (its matrices stay in scalar registers);
-// the closest hit so far travels in the hit record between the segments of a bounce.
-// Ray hand-out for the persistent traversal kernels.  The live paths [0, n) are cut into eight image regions
-// (one per XCD: blockIdx % 8) and each region into 64-ray batches.  The first 7/8 of a region's batches are
-// dealt statically, interleaved over the region's wavefronts (no atomics, spatially balanced); the rest is
-// taken dynamically from one cursor per region (own 128-byte line) so that wavefronts that finish early keep
-// the others' tail short; a wavefront whose region is used up moves on to the next one.
-struct RayFeed {
-  uint32_t n, region_size, waves_per_region, home, region, tried, stat_next, static_eighths, dyn_batch;
-  uint32_t* cursors;  // [8][32]
-  bool in_static;
-
-  __device__ __forceinline__ uint32_t region_len(uint32_t r) const
-  {
-    const uint32_t b = r * region_size;
-    return b < n ? min(n - b, region_size) : 0u;
-  }
-  __device__ __forceinline__ uint32_t static_batches(uint32_t r) const
-  {
-    return ((region_len(r) + kWave - 1u) / kWave) * static_eighths / 8u;
-  }
-  // static_eighths: share of every region that is dealt statically (0..8).  Static dealing costs no atomics
-  // but cannot balance regions of different cost (sky rows vs terrain rows in the primary bounce).
-  __device__ __forceinline__ void init(uint32_t n_, uint32_t* cursors_, uint32_t static_eighths_)
-  {
-    n = n_;
-    cursors = cursors_;
-    static_eighths = static_eighths_;
-    region_size = ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave;
-    waves_per_region = (gridDim.x + 7u) / 8u;
-    home = region = blockIdx.x & 7u;
-    stat_next = blockIdx.x >> 3;
-    tried = 0u;
-    in_static = static_eighths != 0u;
-    // dynamic batches: one atomic hands out this many rays (a cursor line sustains ~30 atomics/us)
-    dyn_batch = n / gridDim.x >= 256u ? 128u : (uint32_t)kWave;
-  }
-  __device__ __forceinline__ bool exhausted() const { return !in_static && tried >= 8u; }
-  // wave-uniform: next batch [begin, end) or false
-  __device__ __forceinline__ bool acquire(uint32_t& begin, uint32_t& end)
-  {
-    if (in_static) {
-      if (stat_next < static_batches(home)) {
-        begin = home * region_size + stat_next * kWave;
-        end = begin + kWave;  // static batches are full batches inside the region
-        stat_next += waves_per_region;
-        return true;
-      }
-      in_static = false;
-    }
-    while (tried < 8u) {
-      const uint32_t len = region_len(region);
-      const uint32_t first = static_batches(region) * kWave;
-      uint32_t base = len;
-      if (threadIdx.x == 0u && first < len &&
-          first + __hip_atomic_load(&cursors[region * 32u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len)
-        base = first + atomicAdd(&cursors[region * 32u], dyn_batch);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base < len) {
-        begin = region * region_size + base;
-        end = region * region_size + min(len, base + dyn_batch);
-        return true;
-      }
-      region = (region + 1u) & 7u;
-      ++tried;
-    }
-    return false;
-  }
-};
-
+// Traversal lengths differ by an order of magnitude between neighbouring rays (a ray that grazes the terrain
+// tests hundreds of boxes, its neighbour a few dozen), so "one wavefront = 64 fixed rays" leaves most lanes idle
+// most of the time (measured: 21 % of lanes active per VALU instruction).  A traversal wavefront therefore lives
+// for the whole launch and every lane that finishes its ray takes the next unprocessed one.  Results are written
+// per slot, so the order in which rays are processed is irrelevant to the output.  One launch handles ONE mesh
+// object (its matrices stay in scalar registers); the closest hit so far travels in the hit record between the
+// segments of a bounce.  The live paths [0, n) of a frame are cut into eight image regions (one per XCD:
+// blockIdx % 8) and each region into 64-ray batches; a share of the batches is dealt statically (no atomics),
+// the rest is taken from one cursor per region (own 128-byte line).
 // RayFeed for a batch of frames (DBatchInfo): count x 8 regions, region (f, r) = eighth r of frame f's live
 // rays, its cursor on frame f's counters.  A wavefront's home keeps the XCD <-> image-region pairing of
 // RayFeed (r = blockIdx & 7) and deals the frames round-robin over the wavefronts of that XCD.  Ranges are
@@ -854,198 +777,11 @@ struct BatchFeed {
   }
 };
 
-constexpr uint32_t kRefillLanes = 20u;  // fetch new rays once this many lanes are idle
-
-template <bool kCount, bool kFirst>
-__global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
-                                                    int work_slot, DeviceCounters* counters)
-{
-  __shared__ uint32_t s_stack[kWideStack * kWave];
-  uint32_t* stack = s_stack + threadIdx.x;
-  const uint32_t n = counters->live[bounce];
-  if (n == 0u) return;
-  const DObject* obj = sc.objects + obj_index;
-  const uint32_t mat = sc.object_material[obj_index];
-  const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
-  if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
-  RayFeed feed;
-  feed.init(n, &counters->work[work_slot][0][0], sc.static_eighths);
-  uint32_t priv_next = 0u, priv_end = 0u;
-
-  bool active = false;
-  bool exact_only = false;
-  uint32_t slot = 0u, cur = 0u, flags = 0u;
-  int sp = 0, best_k = -1;
-  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), od = mk3(0, 0, 0), inv = mk3(0, 0, 0);
-  float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
-  Tally tally;
-  uint32_t ray_boxes = 0u;
-
-  for (;;) {
-    const uint64_t idle_mask = __ballot(!active);
-    const uint32_t idle = (uint32_t)__popcll(idle_mask);
-    const bool more = priv_next < priv_end || !feed.exhausted();
-    if (more && (idle == (uint32_t)kWave || idle >= kRefillLanes)) {
-      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
-      const uint32_t mine = priv_next + rank_below(idle_mask);
-      const uint32_t range_end = priv_end;
-      priv_next = min(priv_end, priv_next + idle);
-      if (!active && mine < range_end) {
-        slot = mine;
-        const float4 o4 = paths.o4[slot];
-        const float4 d4 = paths.d4[slot];
-        ro = xyz(o4);
-        rd = xyz(d4);
-        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
-        float t_in = FLT_MAX;
-        if (!kFirst) {
-          const float carried = hits.tp[slot].x;
-          if (carried >= 0.0f) t_in = carried;
-        }
-        bool go = sc.bvh_node_count != 0u && ray_aabb(ro, rd, ld3(obj->bmin), ld3(obj->bmax));  // path_tracer.cu:84
-        if (go) {
-          const f3 v = xform_vector(obj->inv_m, rd);  // inverse_transform_ray, transform.hpp:51-58
-          scale = ieee_sqrt(dot(v, v));
-          od = v * (1.0f / scale);
-          oo = xform_point(obj->inv_m, ro);
-          inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          exact_only = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z));
-          best_t = t_in;
-          best_k = -1;
-          limit = scale * best_t;
-          cur = sc.root_ref;
-          sp = 0;
-          ray_boxes = 0u;
-          if (!(cur & kLeafBit)) {
-            float tn, tf;
-            if (kCount) { ++tally.boxes; ++ray_boxes; }
-            go = box_pass_inner(ld3(sc.root_min), ld3(sc.root_max), oo, od, inv, exact_only, tn, tf) &&
-                 !box_culled(tn, tf, limit);
-          }
-        }
-        if (go) active = true;
-        else if (kFirst) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-      }
-    }
-    if (__ballot(active) == 0ull) {
-      if (priv_next >= priv_end && feed.exhausted()) break;
-      continue;
-    }
-
-    bool done = false;
-    if (active && !(cur & kLeafBit)) {
-      const float4 w0 = sc.wide[4u * (size_t)cur], w1 = sc.wide[4u * (size_t)cur + 1u];
-      const float4 w2 = sc.wide[4u * (size_t)cur + 2u], w3 = sc.wide[4u * (size_t)cur + 3u];
-      const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
-      const f3 lmin = mk3(w0.x, w0.y, w0.z), lmax = mk3(w0.w, w1.x, w1.y);
-      const f3 rmin = mk3(w1.z, w1.w, w2.x), rmax = mk3(w2.y, w2.z, w2.w);
-      if (kCount) { tally.boxes += 2u; ray_boxes += 2u; }
-      float ln, lf, rn, rf;
-      slab_fast(lmin, lmax, oo, inv, ln, lf);
-      slab_fast(rmin, rmax, oo, inv, rn, rf);
-      const bool l_leaf = (lref & kLeafBit) != 0u, r_leaf = (rref & kLeafBit) != 0u;
-      const float lgap = lf - ln, rgap = rf - rn;
-      const float ltol = (l_leaf ? 1e-4f : 4e-7f) * (fabsf(lf) + fabsf(ln)) + 1e-30f;
-      const float rtol = (r_leaf ? 1e-4f : 4e-7f) * (fabsf(rf) + fabsf(rn)) + 1e-30f;
-      bool go_l = l_leaf ? !(lgap < -ltol) : (lgap > ltol);
-      bool go_r = r_leaf ? !(rgap < -rtol) : (rgap > rtol);
-      const bool l_unsure = !l_leaf && (exact_only || !(lgap > ltol || lgap < -ltol));
-      const bool r_unsure = !r_leaf && (exact_only || !(rgap > rtol || rgap < -rtol));
-      if (__builtin_expect(l_unsure || r_unsure || exact_only, 0)) {
-        if (l_unsure) go_l = slab_exact(lmin, lmax, oo, od, ln, lf);
-        if (r_unsure) go_r = slab_exact(rmin, rmax, oo, od, rn, rf);
-        if (exact_only) {
-          go_l = go_l || l_leaf;
-          go_r = go_r || r_leaf;
-        }
-      }
-      go_l = go_l && !box_culled(ln, lf, limit);
-      go_r = go_r && !box_culled(rn, rf, limit);
-      if (go_l && go_r) {
-        const bool left_first = !(rn < ln);
-        if (sp >= kWideStack) {
-          flags |= kFlagStackOverflow;
-        } else {
-          stack[sp * kWave] = left_first ? rref : lref;
-          ++sp;
-        }
-        cur = left_first ? lref : rref;
-      } else if (go_l || go_r) {
-        cur = go_l ? lref : rref;
-      } else if (sp == 0) {
-        done = true;
-      } else {
-        --sp;
-        cur = stack[sp * kWave];
-      }
-    }
-    if (active && !done && (cur & kLeafBit)) {
-      const uint32_t k = cur & ~kLeafBit;
-      const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
-      if (kCount) ++tally.tris;
-      const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
-      const f3 h = cross(rd, e2);
-      const float a = dot(e1, h);
-      if (!(a > -0.0000001f && a < 0.0000001f)) {
-        const float f = 1.0f / a;
-        const f3 sv = ro - p0;
-        const float u = f * dot(sv, h);
-        if (!(u < 0.0f || u > 1.0f)) {
-          const f3 q = cross(sv, e1);
-          const float w = f * dot(rd, q);
-          if (!(w < 0.0f || u + w > 1.0f)) {
-            const float t = f * dot(e2, q);
-            if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
-              best_t = t;
-              best_k = (int)k;
-              limit = scale * t;
-            }
-          }
-        }
-      }
-      if (sp == 0) {
-        done = true;
-      } else {
-        --sp;
-        cur = stack[sp * kWave];
-      }
-    }
-    if (done) {
-      if (best_k >= 0) {
-        const float4 tc = tris[3u * (size_t)best_k + 2u];
-        const f3 outward = mk3(tc.y, tc.z, tc.w);
-        const f3 p = ro + rd * best_t;
-        const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
-        const f3 nn = side == 0u ? outward : -outward;
-        hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
-        hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
-      } else if (kFirst) {
-        hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-      }
-      if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
-      active = false;
-    }
-  }
-  if (flags) atomicOr(&counters->flags, flags);
-  if (kCount) {
-    uint32_t b = tally.boxes, t = tally.tris;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      b += __shfl_down(b, off, 64);
-      t += __shfl_down(t, off, 64);
-    }
-    if (threadIdx.x == 0u) {
-      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
-      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// variant 3: variant 4's scheme over the four-wide collapse (128-byte nodes: half the dependent loads per ray)
+// variant 3 (default): persistent wavefronts over the four-wide collapse, 64-byte quantised nodes
 // ------------------------------------------------------------------------------------------------
 // Conservative FMA slabs on four children per step, children visited nearest first, optimistic acceptance,
-// one exact test of the winner's parent box (see variant 4 below for the argument), results in batches.
+// one exact test of the winner (finalize below), results written in batches just before a refill.
 #ifndef PT_T4_LDS
 #define PT_T4_LDS 24
 #endif
@@ -1054,10 +790,18 @@ __global__ __launch_bounds__(kWave) void k_traverse(DScene sc, uint32_t obj_inde
 #endif
 constexpr int kLds4 = PT_T4_LDS;  // traversal stack entries per lane in LDS (6 KiB per wavefront); deeper: DScene::spill
 
+// Set a ray aside for the exact redo at the end of the launch (redo_slow_rays).  The entry is written with an
+// agent-scope atomic store: the wavefront that drains the list may run on another XCD (its own L2).
+__device__ __forceinline__ void set_aside(DeviceCounters* counters, uint32_t* slow_list, uint32_t slot)
+{
+  const uint32_t at = atomicAdd(&counters->slow_count, 1u);
+  __hip_atomic_store(&slow_list[at], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool kCount, bool kFirst>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES))) void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
-                                                     int work_slot, DeviceCounters* counters, uint32_t* slow_list,
-                                                     DBatchInfo bi)
+__device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
+                                               int bounce, int work_slot, DeviceCounters* counters, uint32_t* slow_list,
+                                               const DBatchInfo& bi)
 {
   __shared__ uint32_t s_stack[kLds4 * kWave];
   // explicitly an LDS pointer: as a generic pointer the pop below compiles to a flat load
@@ -1093,9 +837,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   Tally tally;
   uint32_t ray_boxes = 0u;
 
+  // entries [0, lds_cap) of a lane's stack live in LDS, the rest in the launch's global overflow area (lds_cap is
+  // kLds4 except in tests that want the overflow path exercised by small scenes)
+  const int lds_cap = (int)sc.lds_cap;
   auto push = [&](uint32_t ref) {
-    if (sp < kLds4) stack[sp * kWave] = ref;
-    else if (sp < kLds4 + (int)sc.spill_cap) sc.spill[(size_t)(sp - kLds4) * sc.spill_stride + gid].x = ref;
+    if (sp < lds_cap) stack[sp * kWave] = ref;
+    else if (sp < lds_cap + (int)sc.spill_cap) sc.spill[(size_t)(sp - lds_cap) * sc.spill_stride + gid].x = ref;
     else {
       flags |= kFlagStackOverflow;
       return;
@@ -1105,8 +852,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
   // the top entry without removing it (kNoChild for an empty stack)
   auto peek = [&]() -> uint32_t {
     const int top = sp - 1;
-    uint32_t r = stack[min(max(top, 0), kLds4 - 1) * kWave];
-    if (__builtin_expect(top >= kLds4, 0)) r = sc.spill[(size_t)(top - kLds4) * sc.spill_stride + gid].x;
+    uint32_t r = stack[min(max(top, 0), lds_cap - 1) * kWave];
+    if (__builtin_expect(top >= lds_cap, 0)) r = sc.spill[(size_t)(top - lds_cap) * sc.spill_stride + gid].x;
     return top >= 0 ? r : kNoChild;
   };
   // the conservative slab pair of one box for this lane's ray, tolerance folded INWARDS: if even that interval is
@@ -1150,7 +897,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
           float en, ef;
           if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u) {
             // a ray grazing the parent's box within rounding: redone in the reference's order by k_slow_rays
-            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+            set_aside(counters, slow_list, slot);
             best_k = -2;
           }
         }
@@ -1225,7 +972,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
                                sc.force_slow == 1u, 0)) {
             // degenerate direction (0/0 or overflow in the slab terms voids the error bound): set aside for
             // k_slow_rays, which walks the tree in the reference's own order
-            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
+            set_aside(counters, slow_list, slot);
             wrote = true;
             go = false;
           } else {
@@ -1285,6 +1032,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
       const uint4 q0 = make_uint4(w0.x, w0.y, w0.z, w0.w), q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
       const uint4 q2 = make_uint4(w2.x, w2.y, w2.z, w2.w), q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
       if (!is_leaf) {
+        if (kCount) ++tally.nodes;
         // 64-byte node: origin + power-of-two grid steps + 8-bit plane coordinates (Wide4Accel::nodes_q).  A plane
         // is origin + q * step, so its slab term is fma(q, step / d, fma(origin, 1/d, -o/d -+ tol)): two terms per
         // axis and node, one fma per plane.  The quantised boxes contain the exact ones, so the walk stays
@@ -1330,7 +1078,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
         cx(1, 3);
         cx(1, 2);
         // the others go on the stack, farthest first
-        if (__builtin_expect(sp + 3 <= kLds4, 1)) {
+        if (__builtin_expect(sp + 3 <= lds_cap, 1)) {
           // room for all three in LDS: write unconditionally, advance only past the ones that count (a slot that
           // does not count is overwritten by the next write or stays above the top)
           stack[sp * kWave] = ref[3];
@@ -1385,300 +1133,27 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAV
     }
   }
   if (flags) atomicOr(&counters->flags, flags);
-  if (kCount) {
-    uint32_t b = tally.boxes, t = tally.tris;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      b += __shfl_down(b, off, 64);
-      t += __shfl_down(t, off, 64);
-    }
-    if (threadIdx.x == 0u) {
-      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
-      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// variant 4: persistent traversal over the two-wide records, conservative FMA slabs, exact acceptance
-// ------------------------------------------------------------------------------------------------
-// Same contract as variant 3 (conservative traversal + the reference's own box test on the parent of every
-// candidate triangle), on the 64-byte two-child records.  Because the slab tests here only have to be
-// conservative they use fused multiply-adds against a per-ray precomputed origin term and a per-ray
-// absolute tolerance that covers the cancellation error of that form; leaf children are tested in the
-// same step as their parent, so a lane does one node per loop iteration.
-constexpr int kLds2 = 16;    // traversal stack entries per lane in LDS (4 KiB per wavefront: 8 wavefronts per SIMD fit)
-
-template <bool kCount, bool kFirst>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_traverse2(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce,
-                 int work_slot, DeviceCounters* counters, uint32_t* slow_list)
-{
-  __shared__ uint32_t s_stack[kLds2 * kWave];
-  uint32_t* stack = s_stack + threadIdx.x;
-  const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
-  const uint32_t n = counters->live[bounce];
-  if (n == 0u) return;
-  const DObject* obj = sc.objects + obj_index;
-  const uint32_t mat = sc.object_material[obj_index];
-  const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
-  if (blockIdx.x >= (n + kWave - 1u) / kWave + 8u) return;  // more wavefronts than batches
-  RayFeed feed;
-  feed.init(n, &counters->work[work_slot][0][0], sc.static_eighths);
-  uint32_t priv_next = 0u, priv_end = 0u;
-
-  bool active = false;
-  bool pending = false;  // traversal finished, result not yet written (done in batches, just before a refill)
-  uint32_t slot = 0u, cur = 0u, flags = 0u;
-  int sp = 0, best_k = -1;
-  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), oo = mk3(0, 0, 0), inv = mk3(0, 0, 0);
-  f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);  // -o/d minus / plus the per-axis error bound of the FMA slab form
-  bool neg_x = false, neg_y = false, neg_z = false;
-  float tmin = 0.0f, best_t = 0.0f, scale = 0.0f, limit = 0.0f;
-  Tally tally;
-  uint32_t ray_boxes = 0u;
-
-  for (;;) {
-    const uint64_t idle_mask = __ballot(!active);
-    const uint32_t idle = (uint32_t)__popcll(idle_mask);
-    const bool more = priv_next < priv_end || !feed.exhausted();
-    if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
-      // results of the rays that finished since the last refill, all at once (the winner's reachability test
-      // costs ~150 instructions: paid per batch of lanes, not per loop iteration)
-      if (pending) {
-      if (best_k >= 0) {
-          // The winner is the closest of ALL candidates; it is the reference's answer iff the reference can reach
-          // it, i.e. iff its parent's box passes the reference's own test (nesting).  If not (a ray grazing
-          // that box within rounding), the ray is redone in the reference's order by k_slow_rays.
-          const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
-          const f3 od = normalize(xform_vector(obj->inv_m, rd));
-          float en, ef;
-          if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u, 0)) {
-            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
-            best_k = -2;
-          }
-        }
-        if (best_k >= 0) {
-          const float4 tc = tris[3u * (size_t)best_k + 2u];
-          const f3 outward = mk3(tc.y, tc.z, tc.w);
-          const f3 p = ro + rd * best_t;
-          const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
-          const f3 nn = side == 0u ? outward : -outward;
-          hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
-          hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
-        } else if (kFirst && best_k == -1) {
-          hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-        }
-        if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
-        pending = false;
-      }
-      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
-      const uint32_t mine = priv_next + rank_below(idle_mask);
-      const uint32_t range_end = priv_end;
-      priv_next = min(priv_end, priv_next + idle);
-      if (!active && mine < range_end) {
-        slot = mine;
-        const float4 o4 = paths.o4[slot];
-        const float4 d4 = paths.d4[slot];
-        ro = xyz(o4);
-        rd = xyz(d4);
-        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
-        float t_in = FLT_MAX;
-        if (!kFirst) {
-          const float carried = hits.tp[slot].x;
-          if (carried >= 0.0f) t_in = carried;
-        }
-        bool go = sc.bvh_node_count != 0u && ray_aabb(ro, rd, ld3(obj->bmin), ld3(obj->bmax));  // path_tracer.cu:84
-        bool wrote = false;
-        if (go) {
-          const f3 v = xform_vector(obj->inv_m, rd);  // inverse_transform_ray, transform.hpp:51-58
-          scale = ieee_sqrt(dot(v, v));
-          const f3 od = v * (1.0f / scale);
-          oo = xform_point(obj->inv_m, ro);
-          inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || sc.force_slow == 1u, 0)) {
-            // degenerate direction (0/0 in the reference's slab test voids the nesting argument):
-            // set aside for k_slow_rays, which walks the tree in the reference's own order
-            slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
-            wrote = true;
-            go = false;
-          } else {
-            // Conservative slab form t = fma(b, 1/d, -o/d).  Against the reference's (b - o)/d it is off by at
-            // most a few ulp of |b/d| + |o/d| per axis; that bound (|b| <= the root box) is folded into the
-            // two origin terms so the near side can only move nearer and the far side farther.
-            const f3 oi = mk3(-(oo.x * inv.x), -(oo.y * inv.y), -(oo.z * inv.z));
-            const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
-            const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
-            const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
-            const f3 tol = mk3(1e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
-                               1e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
-                               1e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
-            oin = oi - tol;
-            oif = oi + tol;
-            neg_x = inv.x < 0.0f;
-            neg_y = inv.y < 0.0f;
-            neg_z = inv.z < 0.0f;
-            best_t = t_in;
-            best_k = -1;
-            limit = scale * best_t;
-            cur = sc.root_ref;
-            sp = 0;
-            ray_boxes = 0u;
-          }
-        }
-        if (go) active = true;
-        else if (kFirst && !wrote) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-      }
-    }
-    if (__ballot(active) == 0ull) {
-      if (priv_next >= priv_end && feed.exhausted()) {
-        if (pending) {
-      if (best_k >= 0) {
-            // The winner is the closest of ALL candidates; it is the reference's answer iff the reference can reach
-            // it, i.e. iff its parent's box passes the reference's own test (nesting).  If not (a ray grazing
-            // that box within rounding), the ray is redone in the reference's order by k_slow_rays.
-            const float4 pb0 = sc.leaf_parent[2u * (size_t)best_k], pb1 = sc.leaf_parent[2u * (size_t)best_k + 1u];
-            const f3 od = normalize(xform_vector(obj->inv_m, rd));
-            float en, ef;
-            if (__builtin_expect(!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u, 0)) {
-              slow_list[atomicAdd(&counters->slow_count, 1u)] = slot;
-              best_k = -2;
-            }
-          }
-          if (best_k >= 0) {
-            const float4 tc = tris[3u * (size_t)best_k + 2u];
-            const f3 outward = mk3(tc.y, tc.z, tc.w);
-            const f3 p = ro + rd * best_t;
-            const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
-            const f3 nn = side == 0u ? outward : -outward;
-            hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
-            hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
-          } else if (kFirst && best_k == -1) {
-            hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-          }
-          if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
-          pending = false;
-        }
-        break;
-      }
-      continue;
-    }
-
-    bool done = false;
-    if (active && !(cur & kLeafBit)) {
-      const float4 w0 = sc.wide[4u * (size_t)cur], w1 = sc.wide[4u * (size_t)cur + 1u];
-      const float4 w2 = sc.wide[4u * (size_t)cur + 2u], w3 = sc.wide[4u * (size_t)cur + 3u];
-      const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
-      if (kCount) { tally.boxes += 2u; ray_boxes += 2u; }
-      // conservative slabs: the near / far plane of each axis is picked by the sign of 1/d, one FMA each
-      const float ln = fmaxf(fmaxf(__builtin_fmaf(neg_x ? w0.w : w0.x, inv.x, oin.x),
-                                   __builtin_fmaf(neg_y ? w1.x : w0.y, inv.y, oin.y)),
-                             __builtin_fmaf(neg_z ? w1.y : w0.z, inv.z, oin.z));
-      const float lf = fminf(fminf(__builtin_fmaf(neg_x ? w0.x : w0.w, inv.x, oif.x),
-                                   __builtin_fmaf(neg_y ? w0.y : w1.x, inv.y, oif.y)),
-                             __builtin_fmaf(neg_z ? w0.z : w1.y, inv.z, oif.z));
-      const float rn = fmaxf(fmaxf(__builtin_fmaf(neg_x ? w2.y : w1.z, inv.x, oin.x),
-                                   __builtin_fmaf(neg_y ? w2.z : w1.w, inv.y, oin.y)),
-                             __builtin_fmaf(neg_z ? w2.w : w2.x, inv.z, oin.z));
-      const float rf = fminf(fminf(__builtin_fmaf(neg_x ? w1.z : w2.y, inv.x, oif.x),
-                                   __builtin_fmaf(neg_y ? w1.w : w2.z, inv.y, oif.y)),
-                             __builtin_fmaf(neg_z ? w2.x : w2.w, inv.z, oif.z));
-      // skip a child only if its (already widened) slab interval is empty by a relative margin, lies beyond
-      // the closest hit, or behind the origin (NaN compares false -> visited)
-      const bool go_l = !((lf - ln) < -1e-4f * (fabsf(ln) + fabsf(lf))) && !box_culled(ln, lf, limit);
-      const bool go_r = !((rf - rn) < -1e-4f * (fabsf(rn) + fabsf(rf))) && !box_culled(rn, rf, limit);
-      if (go_l && go_r) {
-        const bool left_first = !(rn < ln);
-        const uint32_t later = left_first ? rref : lref;
-        if (sp < kLds2) {
-          stack[sp * kWave] = later;
-          ++sp;
-        } else if (sp < kLds2 + (int)sc.spill_cap) {
-          sc.spill[(size_t)(sp - kLds2) * sc.spill_stride + gid].x = later;
-          ++sp;
-        } else {
-          flags |= kFlagStackOverflow;
-        }
-        cur = left_first ? lref : rref;
-      } else if (go_l || go_r) {
-        cur = go_l ? lref : rref;
-      } else if (sp == 0) {
-        done = true;
-      } else {
-        --sp;
-        cur = sp < kLds2 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds2) * sc.spill_stride + gid].x;
-      }
-    }
-    if (active && !done && (cur & kLeafBit)) {
-      // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
-      const uint32_t k = cur & ~kLeafBit;
-      const float4 ta = tris[3u * (size_t)k], tb = tris[3u * (size_t)k + 1u], tc = tris[3u * (size_t)k + 2u];
-      if (kCount) ++tally.tris;
-      const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
-      const f3 h = cross(rd, e2);
-      const float a = dot(e1, h);
-      if (!(a > -0.0000001f && a < 0.0000001f)) {
-        const float f = 1.0f / a;
-        const f3 sv = ro - p0;
-        const float u = f * dot(sv, h);
-        if (!(u < 0.0f || u > 1.0f)) {
-          const f3 qv = cross(sv, e1);
-          const float w = f * dot(rd, qv);
-          if (!(w < 0.0f || u + w > 1.0f)) {
-            const float t = f * dot(e2, qv);
-            // taken optimistically; whether the reference can reach it is checked once, on the final winner
-            if (!(t < tmin) && (t < best_t || (t == best_t && (int)k > best_k))) {
-              best_t = t;
-              best_k = (int)k;
-              limit = scale * t;
-            }
-          }
-        }
-      }
-      if (sp == 0) {
-        done = true;
-      } else {
-        --sp;
-        cur = sp < kLds2 ? stack[sp * kWave] : sc.spill[(size_t)(sp - kLds2) * sc.spill_stride + gid].x;
-      }
-    }
-    if (done) {
-      active = false;
-      pending = true;
-    }
-  }
-  if (flags) atomicOr(&counters->flags, flags);
-  if (kCount) {
-    uint32_t b = tally.boxes, t = tally.tris;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      b += __shfl_down(b, off, 64);
-      t += __shfl_down(t, off, 64);
-    }
-    if (threadIdx.x == 0u) {
-      atomicAdd(&counters->box_tests[bounce], (unsigned long long)b);
-      atomicAdd(&counters->tri_tests[bounce], (unsigned long long)t);
-    }
-  }
+  if (kCount) flush_tally(tally, counters, bounce, false);
 }
 
 // Rays a persistent traversal launch set aside (a direction with a zero / subnormal component, or a winner whose
-// parent box the ray only grazes): redone with EXACT box decisions -- the culled near-first walk of variants 1
-// and 2 (mesh_closest_wide: every inner box decided like the reference's ray_aabb, also for NaN / infinite
-// slab terms), which returns the reference's hit in ~50 box tests instead of the ~125 (worst case thousands)
-// of the reference's own order.  One workgroup; the list is almost always empty.
+// parent box the ray only grazes): redone with EXACT box decisions -- the culled near-first walk
+// (mesh_closest_wide: every inner box decided like the reference's ray_aabb, also for NaN / infinite slab terms),
+// which returns the reference's hit in ~50 box tests instead of the ~125 (worst case thousands) of the reference's
+// own order.  Run by the LAST wavefront of the traversal launch to finish (k_traverse4's epilogue): the list is
+// almost always empty, and a separate one-wavefront launch for it was a bubble on the stream every bounce (it
+// waited for a wavefront slot behind the other stream's persistent wavefronts: 10 % of the kernel time of round 1).
+// Its traversal stack lives in global memory (DScene::slow_stack, [depth][lane]): this code is off the fast path.
 template <bool kFirst>
-__global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_index, DPaths paths, DHits hits,
-                                                     const uint32_t* slow_list, DeviceCounters* counters, int bounce)
+__device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
+                                            const uint32_t* slow_list, uint32_t count, DeviceCounters* counters)
 {
-  __shared__ uint32_t s_stack[kWideStack * kWave];
-  const uint32_t count = counters->slow_count;
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const uint32_t tri_base = sc.object_tri_base[obj_index];
   uint32_t flags = 0u;
   for (uint32_t i = threadIdx.x; i < count; i += kWave) {
-    const uint32_t slot = slow_list[i];
+    const uint32_t slot = __hip_atomic_load(&slow_list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Ray ray = load_ray(paths, slot);
     if (!kFirst) {
       const float carried = hits.tp[slot].x;
@@ -1687,9 +1162,9 @@ __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_ind
     float best_t = ray.tmax;
     int best_k = -1;
     Tally unused;
-    // the object's world box first (path_tracer.cu:84): the persistent kernels test it only for their winners
+    // the object's world box first (path_tracer.cu:84): the persistent kernel tests it only for its winners
     if (ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax)))
-      mesh_closest_wide<false>(ray, sc, obj, tri_base, best_t, best_k, s_stack + threadIdx.x, flags, unused);
+      mesh_closest_wide<false>(ray, sc, obj, tri_base, best_t, best_k, sc.slow_stack + threadIdx.x, flags, unused);
     if (best_k >= 0) {
       const float4 tc = sc.tris[3u * ((size_t)tri_base + (uint32_t)best_k) + 2u];
       const f3 outward = mk3(tc.y, tc.z, tc.w);
@@ -1703,10 +1178,30 @@ __global__ __launch_bounds__(kWave) void k_slow_rays(DScene sc, uint32_t obj_ind
     }
   }
   if (flags) atomicOr(&counters->flags, flags);
-  __syncthreads();
+}
+
+template <bool kCount, bool kFirst>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES)))
+void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce, int work_slot,
+                 DeviceCounters* counters, uint32_t* slow_list, DBatchInfo bi)
+{
+  traverse4_walk<kCount, kFirst>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+  // Epilogue: every wavefront signs off; the last one redoes the rays that were set aside.  The list entries were
+  // written with agent-scope atomic stores; waiting for this wavefront's own stores before the sign-off and reading
+  // the list with agent-scope loads orders them without a full L2 write-back per wavefront.
+  uint32_t prev = 0u;
+  if (threadIdx.x == 0u) {
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wavefront's list entries have landed
+    prev = __hip_atomic_fetch_add(&counters->waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+  if (prev + 1u != gridDim.x) return;
+  const uint32_t count = __hip_atomic_load(&counters->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (count != 0u) redo_slow_rays<kFirst>(sc, obj_index, paths, hits, slow_list, count, counters);
   if (threadIdx.x == 0u) {
     counters->slow_rays[bounce] += count;
     counters->slow_count = 0u;
+    counters->waves_done = 0u;
   }
 }
 
@@ -1787,7 +1282,9 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   }
   if (kLast) {
     const uint64_t live = __ballot(hit);
-    if ((threadIdx.x & 63u) == 0u) chunk_counts[s / kChunk] = (uint32_t)__popcll(live);
+    // a wavefront beyond the live range (s >= n) owns no chunk: k_scan reads ceil(n / 64) entries, and in a batch
+    // the next entries belong to the next frame
+    if ((threadIdx.x & 63u) == 0u && s < n) chunk_counts[s / kChunk] = (uint32_t)__popcll(live);
   }
 }
 
@@ -2196,44 +1693,17 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
   else
     hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
 }
-void launch_slow_rays(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                      const uint32_t* slow_list, DeviceCounters* counters, int bounce)
-{
-  if (first) hipLaunchKernelGGL((k_slow_rays<true>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters, bounce);
-  else hipLaunchKernelGGL((k_slow_rays<false>), dim3(1), dim3(kWave), 0, s, scene, obj_index, paths, hits, slow_list, counters, bounce);
-}
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
-                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves, int variant,
+                     int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                      uint32_t* slow_list, const DBatchInfo& bi)
 {
-  // only variant 3 understands batches of frames (the context enforces bi.count == 1 for the others)
   const dim3 grid(waves), block(kWave);
-  if (variant == 4) {
-    if (count_tests) {
-      if (first) hipLaunchKernelGGL((k_traverse2<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
-      else hipLaunchKernelGGL((k_traverse2<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
-    } else {
-      if (first) hipLaunchKernelGGL((k_traverse2<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
-      else hipLaunchKernelGGL((k_traverse2<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list);
-    }
-    return;
-  }
-  if (variant == 3) {
-    if (count_tests) {
-      if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-      else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-    } else {
-      if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-      else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-    }
-    return;
-  }
   if (count_tests) {
-    if (first) hipLaunchKernelGGL((k_traverse<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
-    else hipLaunchKernelGGL((k_traverse<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+    if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+    else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
   } else {
-    if (first) hipLaunchKernelGGL((k_traverse<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
-    else hipLaunchKernelGGL((k_traverse<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters);
+    if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+    else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
   }
 }
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,

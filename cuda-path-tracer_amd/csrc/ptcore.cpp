@@ -39,9 +39,14 @@ static thread_local std::string g_create_error;
 constexpr uint64_t kAutoFrameBytes = 24ull << 30;
 
 // The frames in flight run on separate HIP streams, and streams only overlap when they sit on different
-// hardware queues; the runtime's default is 4 queues per process.  Ask for more before the runtime starts
-// (no effect if the application has set the variable or has already initialised HIP).
-__attribute__((constructor)) static void ptc_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// hardware queues; the runtime's default is 4 queues per process.  Ask for more before this library's first HIP
+// call (no effect if the application has set the variable or has already initialised HIP itself: such an
+// application exports GPU_MAX_HW_QUEUES on its own, see ptcore.h).
+static void request_hw_queues()
+{
+  static const int once = setenv("GPU_MAX_HW_QUEUES", "24", 0);
+  (void)once;
+}
 
 struct ptc_ctx {
   int device = 0;
@@ -70,7 +75,8 @@ struct ptc_ctx {
     DHits hits{};
     uint32_t* chunk_counts = nullptr;
     uint32_t* chunk_offsets = nullptr;
-    uint32_t* slow_list = nullptr;  // slots of rays set aside for k_slow_rays
+    uint32_t* slow_list = nullptr;  // slots of rays set aside for the exact redo at the end of a traversal launch
+    uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint2* spill = nullptr;         // traversal stack overflow area of this slot's launches (DScene::spill)
     size_t spill_elems = 0;
     DFrame stage{};
@@ -125,7 +131,7 @@ struct ptc_ctx {
   bool have_cam = false;
   uint64_t frames = 0;
 
-  int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse, conservative FMA slabs, exact check of the winner (default); 4: same over two-wide records; 2: exact tests in the loop 0: reference-order traversal, 1: culled near-first traversal, 2: 1 + persistent lanes (default)
+  int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse, conservative FMA slabs, exact check of the winner (default); 0: reference-order traversal; 1: culled near-first traversal with exact box decisions
   struct Segment {
     bool mesh;
     uint32_t begin, end;  // object range (mesh: one object)
@@ -134,6 +140,7 @@ struct ptc_ctx {
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
+  uint32_t lds_entries = 24;  // == kLds4 in pt_kernels.hip (PT_T4_LDS); fewer only through "debug_lds_entries"
   int force_slow = 0;
 
   // measurement
@@ -148,6 +155,8 @@ struct ptc_ctx {
   std::vector<hipEvent_t> free_events;
   double trace_ms[kMaxBounces] = {};
   uint32_t trace_launches[kMaxBounces] = {};
+  double denoise_ms = 0.0;               // A-Trous passes (TimedLaunch::bounce == -1)
+  uint32_t denoise_passes = 0;
 };
 
 namespace {
@@ -312,6 +321,7 @@ int ptc_abi_version(void) { return PTC_ABI_VERSION; }
 int ptc_device_count(int* count)
 {
   if (!count) return PTC_ERR_INVALID;
+  request_hw_queues();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) {
@@ -329,6 +339,7 @@ int ptc_create(const ptc_config* config, ptc_ctx** out)
 {
   if (!out) return fail(nullptr, PTC_ERR_INVALID, "out is NULL");
   *out = nullptr;
+  request_hw_queues();
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     (void)hipGetLastError();
@@ -428,7 +439,8 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (node_count && depth + 2u > (uint32_t)kStackDepth)
     return fail(ctx, PTC_ERR_STACK, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack");
 
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // iterations queued or in flight were asked for against the OLD scene: trace them before it goes away
+  if (int rc = sync_frames(ctx)) return rc;
   free_pool(ctx->scene_allocs);
   ctx->has_scene = false;
   DScene d{};
@@ -486,16 +498,11 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.force_slow = (uint32_t)ctx->force_slow;
   d.spill = nullptr;
   d.spill_stride = ctx->traverse_waves * kWave;
-  // stack need: one entry per level of the two-wide tree, up to three per level of the four-wide collapse;
-  // whatever exceeds the LDS part (16 entries) goes to this per-thread overflow area
+  // stack need of the four-wide walk: up to three entries per level; whatever exceeds the LDS part (24 entries)
+  // goes to this per-thread overflow area (the areas themselves belong to the frame slots, batch_begin)
   d.spill_cap = 0;
-  if (node_count) {
-    // beyond the LDS part: 16 entries (two-wide kernel) / 24 (four-wide kernel)
-    const uint32_t need2 = depth + 2u > 16u ? depth + 2u - 16u : 0u;
-    const uint32_t need4 = 3u * w4.depth + 2u > 24u ? 3u * w4.depth + 2u - 24u : 0u;
-    const uint32_t need = std::max(need2, need4);
-    d.spill_cap = need;  // the areas themselves belong to the frame slots (batch_begin)
-  }
+  d.lds_cap = ctx->lds_entries;
+  if (node_count) d.spill_cap = 3u * w4.depth + 2u > d.lds_cap ? 3u * w4.depth + 2u - d.lds_cap : 0u;
   ctx->bvh4_nodes = w4.node_count;
   ctx->bvh4_depth = w4.depth;
   std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
@@ -533,6 +540,15 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   if (int rc = sync_frames(ctx)) return rc;
   free_slots(ctx);
   free_pool(ctx->frame_allocs);
+  // nothing below is usable until this call has succeeded (frame_ready / ptc_download / ptc_present check these)
+  ctx->pix_capacity = ctx->pix_count = 0;
+  ctx->width = ctx->height = 0;
+  ctx->fb = DFrame{};
+  ctx->den_a = ctx->den_b = ctx->den_pos = nullptr;
+  ctx->result = nullptr;
+  ctx->pack_buf = nullptr;
+  ctx->rgba_buf = nullptr;
+  ctx->have_cam = false;
   const size_t P = (size_t)width * height;
   auto& pool = ctx->frame_allocs;
   const size_t chunks = (P + kChunk - 1) / kChunk;
@@ -577,6 +593,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, (size_t)B * chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, (size_t)B * chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.slow_stack, (size_t)kStackDepth * kWave)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.counters, (size_t)B)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(sl.counters, 0, sizeof(DeviceCounters) * (size_t)B, ctx->stream));
     sl.bi = DBatchInfo{};
@@ -643,6 +660,11 @@ int ptc_set_interleave(ptc_ctx* ctx, uint32_t rank, uint32_t nranks, uint32_t bl
 int ptc_restart(ptc_ctx* ctx)
 {
   if (!ctx) return PTC_ERR_INVALID;
+  // Iterations still queued are traced first, not dropped: the reference has rendered them by the time restart()
+  // runs (path_trace is synchronous there), and a present between restart and the next path_trace shows them.
+  // A viewer restarts after it has presented, i.e. with an empty queue, so this costs nothing where it matters.
+  if (!ctx->pending.empty())
+    if (int rc = flush_pending(ctx)) return rc;
   ctx->iteration = 0;
   return PTC_OK;
 }
@@ -684,7 +706,7 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 4) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant");
+  if (!ctx || (variant != 0 && variant != 1 && variant != 3)) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1 or 3)");
   if (variant == ctx->trace_variant) return PTC_OK;
   if (int rc = flush_pending(ctx)) return rc;
   ctx->trace_variant = variant;
@@ -705,6 +727,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "traverse_waves out of range");
     if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set traverse_waves before ptc_upload_scene");
     ctx->traverse_waves = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "debug_lds_entries") == 0) {
+    if (value < 1 || value > 24) return fail(ctx, PTC_ERR_INVALID, "debug_lds_entries must be in [1,24]");
+    if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set debug_lds_entries before ptc_upload_scene");
+    ctx->lds_entries = (uint32_t)value;
     return PTC_OK;
   }
   if (std::strcmp(name, "debug_force_slow") == 0) {
@@ -795,6 +823,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   DPaths in = sl.paths[sl.cur], out = sl.paths[sl.cur ^ 1];
   DScene scene = ctx->scene;
   scene.spill = sl.spill;
+  scene.slow_stack = sl.slow_stack;
   // HIP events around each launch of the dominant (closest-hit) kernel, on the stream it runs on
   auto timed_begin = [&](ptc_ctx::TimedLaunch& tl) -> int {
     if (!ctx->time_trace) return PTC_OK;
@@ -815,7 +844,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     ctx->timed.push_back(tl);
     return PTC_OK;
   };
-  if (ctx->trace_variant >= 2) {
+  if (ctx->trace_variant == 3) {
     // closest hit = the object list walked as segments (see launch_spheres / launch_traverse)
     for (size_t k = 0; k < ctx->segments.size(); ++k) {
       const auto& seg = ctx->segments[k];
@@ -834,9 +863,8 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         const uint64_t rays0 = (uint64_t)sl.bi.count * ctx->pix_count;
         const uint32_t waves = (uint32_t)std::min<uint64_t>(ctx->traverse_waves, std::max<uint64_t>(1024u, (rays0 / 3072u + 7u) & ~7ull));
         launch_traverse(sl.stream, scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
-                        ctx->count_tests, waves, ctx->trace_variant, sl.slow_list, sl.bi);
+                        ctx->count_tests, waves, sl.slow_list, sl.bi);
         if (int rc = timed_end(tl)) return rc;
-        if (ctx->trace_variant >= 3) launch_slow_rays(sl.stream, scene, seg.begin, first, in, sl.hits, sl.slow_list, sl.counters, bounce);
       } else {
         launch_spheres(sl.stream, scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
                        sl.chunk_counts, sl.counters, sl.bi);
@@ -1019,7 +1047,23 @@ int ptc_denoise(ptc_ctx* ctx)
   float4* front = ctx->den_b;
   if (ctx->den.filter_size >= 1) launch_denoise_positions(ctx->stream, ctx->cam, ctx->pix_count, ctx->fb.nd4, ctx->den_pos);
   for (int step = 1; step <= ctx->den.filter_size; step *= 2) {
+    ptc_ctx::TimedLaunch tl{nullptr, nullptr, -1};
+    if (ctx->time_trace) {
+      for (hipEvent_t* e : {&tl.start, &tl.stop}) {
+        if (!ctx->free_events.empty()) {
+          *e = ctx->free_events.back();
+          ctx->free_events.pop_back();
+        } else {
+          HIP_TRY(ctx, hipEventCreate(e));
+        }
+      }
+      HIP_TRY(ctx, hipEventRecord(tl.start, ctx->stream));
+    }
     launch_denoise_pass(ctx->stream, ctx->cam, ctx->pix_count, color, ctx->fb.nd4, ctx->den_pos, back, step, prm);
+    if (ctx->time_trace) {
+      HIP_TRY(ctx, hipEventRecord(tl.stop, ctx->stream));
+      ctx->timed.push_back(tl);
+    }
     const float4* new_color = back;
     float4* new_back = front;
     float4* new_front = back;
@@ -1126,8 +1170,13 @@ static int drain_timed(ptc_ctx* ctx)
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventSynchronize(tl.stop));
     HIP_TRY(ctx, hipEventElapsedTime(&ms, tl.start, tl.stop));
-    ctx->trace_ms[tl.bounce] += ms;
-    ctx->trace_launches[tl.bounce] += 1u;
+    if (tl.bounce < 0) {
+      ctx->denoise_ms += ms;
+      ctx->denoise_passes += 1u;
+    } else {
+      ctx->trace_ms[tl.bounce] += ms;
+      ctx->trace_launches[tl.bounce] += 1u;
+    }
     ctx->free_events.push_back(tl.start);
     ctx->free_events.push_back(tl.stop);
   }
@@ -1151,6 +1200,8 @@ int ptc_reset_profile(ptc_ctx* ctx)
   if (int rc = drain_timed(ctx)) return rc;
   std::memset(ctx->trace_ms, 0, sizeof ctx->trace_ms);
   std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
+  ctx->denoise_ms = 0.0;
+  ctx->denoise_passes = 0;
   const size_t off = offsetof(DeviceCounters, paths), end = offsetof(DeviceCounters, work);
   for (auto& sl : ctx->slots)
     for (int k = 0; k < sl.capacity; ++k)
@@ -1179,12 +1230,15 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
       out->max_ray_cycles[b] = std::max(out->max_ray_cycles[b], host.max_ray_cycles[b]);
       out->max_wave_cycles[b] = std::max(out->max_wave_cycles[b], host.max_wave_cycles[b]);
       out->slow_rays[b] += host.slow_rays[b];
+      out->node_visits[b] += host.node_visits[b];
     }
   }
   for (int b = 0; b < PTC_MAX_BOUNCES_CAP; ++b) {
     out->trace_ms[b] = ctx->trace_ms[b];
     out->trace_launches[b] = ctx->trace_launches[b];
   }
+  out->denoise_ms = ctx->denoise_ms;
+  out->denoise_passes = ctx->denoise_passes;
   return PTC_OK;
 }
 
@@ -1194,44 +1248,110 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   if (!ctx || !rays || !hit_t || !hit_normal || !hit_material || !hit_side) return PTC_ERR_INVALID;
   if (!ctx->has_scene) return fail(ctx, PTC_ERR_NO_SCENE, "no scene uploaded");
   if (n == 0) return PTC_OK;
+  if (n > 0x7fffffffu) return fail(ctx, PTC_ERR_INVALID, "too many rays");
   if (int rc = bind_device(ctx)) return rc;
+  if (int rc = flush_pending(ctx)) return rc;
+  // The default schedule (variant 3) is the production closest-hit stage itself: the object list walked as sphere /
+  // mesh segments (k_spheres, k_traverse4 and its exact redo), fed with the caller's rays instead of path state.
+  // Path rays know two t_min values (1e-4, and 1e-5 after a dielectric: a flag bit) and start every bounce with
+  // t_max = FLT_MAX; a caller's t_max enters as the "closest hit so far" the segments carry in the hit record.
+  // Rays with another t_min take the one-wavefront-per-64-rays kernel with exact box decisions (variant 1).
+  bool path_like = ctx->trace_variant == 3;
+  for (uint32_t i = 0; i < n && path_like; ++i) {
+    const float tmin = rays[8u * (size_t)i + 3u], tmax = rays[8u * (size_t)i + 7u];
+    path_like = (tmin == 1e-4f || tmin == 1e-5f) && tmax >= 0.0f;
+  }
+  constexpr uint32_t kUntouched = 0x7fffffffu;  // material field of a record no segment has written: a miss
   std::vector<void*> pool;
   float4 *ro = nullptr, *rd = nullptr;
   DHits hits{};
+  uint32_t *chunk_counts = nullptr, *slow_list = nullptr, *slow_stack = nullptr;
+  uint2* spill = nullptr;
+  DeviceCounters* counters = nullptr;
   int rc = dev_alloc(ctx, pool, &ro, n);
   if (!rc) rc = dev_alloc(ctx, pool, &rd, n);
   if (!rc) rc = dev_alloc(ctx, pool, &hits.tp, n);
   if (!rc) rc = dev_alloc(ctx, pool, &hits.nm, n);
+  if (!rc && path_like) {
+    rc = dev_alloc(ctx, pool, &chunk_counts, (size_t)n / kChunk + 1u);
+    if (!rc) rc = dev_alloc(ctx, pool, &slow_list, n);
+    if (!rc) rc = dev_alloc(ctx, pool, &slow_stack, (size_t)kStackDepth * kWave);
+    if (!rc) rc = dev_alloc(ctx, pool, &spill, (size_t)ctx->scene.spill_cap * ctx->scene.spill_stride);
+    if (!rc) rc = dev_alloc(ctx, pool, &counters, 1);
+  }
   if (rc) {
     free_pool(pool);
     return rc;
   }
   std::vector<float4> ho(n), hd(n), tp(n), nm(n);
+  float untouched_bits;
+  std::memcpy(&untouched_bits, &kUntouched, 4);
   for (uint32_t i = 0; i < n; ++i) {
     const float* r = rays + 8u * (size_t)i;
-    ho[i] = make_float4(r[0], r[1], r[2], r[3]);
-    hd[i] = make_float4(r[4], r[5], r[6], r[7]);
+    if (path_like) {
+      const uint32_t flag = r[3] == 1e-5f ? 0x80000000u : 0u;
+      float fbits;
+      std::memcpy(&fbits, &flag, 4);
+      ho[i] = make_float4(r[0], r[1], r[2], fbits);
+      hd[i] = make_float4(r[4], r[5], r[6], 0.0f);
+      tp[i] = make_float4(r[7], 0.0f, 0.0f, 0.0f);
+      nm[i] = make_float4(0.0f, 0.0f, 0.0f, untouched_bits);
+    } else {
+      ho[i] = make_float4(r[0], r[1], r[2], r[3]);
+      hd[i] = make_float4(r[4], r[5], r[6], r[7]);
+    }
   }
   hipError_t e = hipMemcpyAsync(ro, ho.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(rd, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
+  if (e == hipSuccess && path_like) {
+    e = hipMemcpyAsync(hits.tp, tp.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits.nm, nm.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(DeviceCounters), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&counters->live[0], &n, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      DScene scene = ctx->scene;
+      scene.spill = spill;
+      scene.slow_stack = slow_stack;
+      DPaths paths{ro, rd, nullptr};
+      DBatchInfo bi{};
+      bi.stride = n;
+      bi.chunk_stride = n / kChunk + 1u;
+      bi.count = 1u;
+      const uint32_t waves = std::min<uint32_t>(ctx->traverse_waves, std::max<uint32_t>(8u, ((n / (4u * kWave)) + 7u) & ~7u));
+      int work_slot = 0;
+      for (size_t k = 0; k < ctx->segments.size() && work_slot < kWorkSlots; ++k) {
+        const auto& seg = ctx->segments[k];
+        if (seg.mesh)
+          launch_traverse(ctx->stream, scene, seg.begin, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, bi);
+        else
+          launch_spheres(ctx->stream, scene, seg.begin, seg.end, false, k + 1 == ctx->segments.size(), paths, hits, n, 0,
+                         chunk_counts, counters, bi);
+      }
+      e = hipGetLastError();
+    }
+  } else if (e == hipSuccess) {
     launch_intersect(ctx->stream, ctx->scene, ro, rd, n, hits, ctx->misc_counters, ctx->trace_variant == 0 ? 0 : 1);
     e = hipGetLastError();
   }
+  uint32_t dev_flags = 0u;
   if (e == hipSuccess) e = hipMemcpyAsync(tp.data(), hits.tp, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(nm.data(), hits.nm, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && path_like)
+    e = hipMemcpyAsync(&dev_flags, &counters->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   free_pool(pool);
   if (e != hipSuccess) return fail(ctx, PTC_ERR_HIP, std::string("intersect_rays: ") + hipGetErrorString(e));
+  if (dev_flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow in ptc_intersect_rays");
   for (uint32_t i = 0; i < n; ++i) {
-    hit_t[i] = tp[i].x;
+    uint32_t ms;
+    std::memcpy(&ms, &nm[i].w, 4);
+    const bool miss = path_like ? (ms & 0x7fffffffu) == kUntouched : tp[i].x < 0.0f;
+    hit_t[i] = miss ? -1.0f : tp[i].x;
     hit_normal[3u * i] = nm[i].x;
     hit_normal[3u * i + 1u] = nm[i].y;
     hit_normal[3u * i + 2u] = nm[i].z;
-    uint32_t ms;
-    std::memcpy(&ms, &nm[i].w, 4);
-    hit_material[i] = ms & 0x7fffffffu;
-    hit_side[i] = (uint8_t)(ms >> 31);
+    hit_material[i] = miss ? 0u : (ms & 0x7fffffffu);
+    hit_side[i] = miss ? (uint8_t)0 : (uint8_t)(ms >> 31);
   }
   return PTC_OK;
 }

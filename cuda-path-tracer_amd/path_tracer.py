@@ -212,7 +212,9 @@ class PathTracer:
                 "max_box_tests": [int(x) for x in p.max_box_tests[:n]],
                 "max_ray_cycles": [int(x) for x in p.max_ray_cycles[:n]],
                 "max_wave_cycles": [int(x) for x in p.max_wave_cycles[:n]],
-                "slow_rays": [int(x) for x in p.slow_rays[:n]]}
+                "slow_rays": [int(x) for x in p.slow_rays[:n]],
+                "node_visits": [int(x) for x in p.node_visits[:n]],
+                "denoise_ms": float(p.denoise_ms), "denoise_passes": int(p.denoise_passes)}
 
     def intersect_rays(self, rays):
         """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PTC_ABI_VERSION 1
+#define PTC_ABI_VERSION 2
 
 typedef enum ptc_status {
   PTC_OK = 0,
@@ -132,6 +132,8 @@ typedef struct ptc_stats {
 /* Measurement support (no reference equivalent; the reference only has a wall-clock Stopwatch, cli.cpp:27-60).
  * Per bounce index, summed over every streaming frame traced since ptc_reset_profile:
  *   paths      live paths that entered the bounce (= closest-hit queries = rays)
+ *   node_visits BVH node records fetched by the closest-hit kernel (counting runs; one four-child 64-byte record
+ *              in the default kernel, one two-child record in variant 1, one 32-byte node in variant 0)
  *   trace_ms   duration of the closest-hit kernel, from HIP events recorded on the context's stream
  *              around each launch (only while events are enabled)
  *   box_tests  ray/AABB tests of BVH nodes, tri_tests  ray/triangle tests (only while counting is
@@ -145,7 +147,11 @@ typedef struct ptc_profile {
   uint32_t max_box_tests[PTC_MAX_BOUNCES_CAP]; /* longest single traversal seen (counting runs) */
   uint32_t max_ray_cycles[PTC_MAX_BOUNCES_CAP];  /* ... in shader clocks, and the longest-lived wavefront */
   uint32_t max_wave_cycles[PTC_MAX_BOUNCES_CAP];
-  uint64_t slow_rays[PTC_MAX_BOUNCES_CAP];   /* rays redone by the reference-order fallback kernel (always counted) */
+  uint64_t slow_rays[PTC_MAX_BOUNCES_CAP];   /* rays redone with exact box decisions at the end of a traversal launch (always counted) */
+  uint64_t node_visits[PTC_MAX_BOUNCES_CAP]; /* BVH node records fetched (counting runs): SURVEY 8(d)'s N_node */
+  double denoise_ms;                         /* summed duration of the A-Trous passes (HIP events, while events are enabled) */
+  uint32_t denoise_passes;
+  uint32_t reserved;
 } ptc_profile;
 
 typedef struct ptc_ctx ptc_ctx;
@@ -185,15 +191,14 @@ int ptc_set_method(ptc_ctx* ctx, int method);                       /* PathTrace
 int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces);             /* static max_bounces = 50, path_tracer.cu:27 */
 int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* PathTracer::atrous_denoiser */
 /* Closest-hit kernel variant (speed only; all return the same hits, bit for bit -- same box decisions, same
- * tie rule; 0-2 and 4 exist to cross-check the default on the GPU):
+ * tie rule; 0 and 1 exist to cross-check the default on the GPU):
  *   3 (default) = persistent wavefronts whose lanes fetch the next ray as soon as their own is finished, over the
  *                 tree collapsed to four children per 64-byte quantised node; box decisions only conservative, the
  *                 winning triangle re-checked against its parent's box with the reference's arithmetic
  *                 (sufficient: see DESIGN.md "nesting"); objects walked as sphere / mesh segments; the only
  *                 variant that traces several iterations per launch ("batch_frames")
- *   4           = the same scheme over two-child 64-byte records
- *   2           = persistent wavefronts, exact box decisions inside the loop
- *   1           = culled near-first traversal, one wavefront per 64 fixed paths
+ *   1           = culled near-first traversal with exact box decisions, one wavefront per 64 fixed paths (the
+ *                 walk the default uses for the few rays it sets aside)
  *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no
  *                 t culling) */
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
@@ -215,7 +220,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   use keeps eight frames in flight as well (config 5, 1 spp + denoise per 1080p frame: 1.6 ms)
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 3 = 3/8)
- *   "debug_force_slow" test hook: route every ray through the reference-order fallback kernel */
+ *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small
+ *                      scenes exercise the global overflow area (1..24; before ptc_upload_scene)
+ *   "debug_force_slow" test hook: route every ray through the exact redo at the end of the traversal launch */
 int ptc_set_param(ptc_ctx* ctx, const char* name, int value);
 
 /* ---- the hot path ---- */

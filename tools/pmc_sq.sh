@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_sq.sh <tag> <scene> <variant>   -- SQ counters only (two passes)
-TAG=${1:-pmc}; SC=${2:-heightfield}; VAR=${3:-2}
+TAG=${1:-pmc}; SC=${2:-heightfield}; VAR=${3:-3}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
