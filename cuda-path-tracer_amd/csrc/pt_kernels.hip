@@ -258,6 +258,37 @@ __device__ __forceinline__ void slab_fast(const f3 bmin, const f3 bmax, const f3
   t_far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 }
 
+// Slab interval of a box FOR CULLING ONLY (never for a decision the reference takes), valid also when a direction
+// component is zero or so small that its reciprocal is not finite.  On such an axis the ray keeps its coordinate:
+// the interval is everything when the origin lies within the box's extent (boundary included, plus a margin far
+// beyond rounding: a triangle test can accept a ray that runs along the box face) and nothing otherwise.  The
+// products of slab_fast are 0 * inf = NaN exactly in the case that matters -- origin on a box plane -- and fminf /
+// fmaxf then pick the other operand, which moved such a box to t = +inf: rays through mesh vertices, along
+// triangle edges or down a box face lost their hit (found by the adversarial rays of
+// tests/test_gpu_schedules.py::test_benchmark_size_rays_against_oracle).
+__device__ __forceinline__ void slab_cull(const f3 bmin, const f3 bmax, const f3 oo, const f3 inv, float& t_near, float& t_far)
+{
+  const float kInf = __builtin_inff();
+  auto axis = [&](float lo_b, float hi_b, float o, float r, float& lo, float& hi) {
+    if (finite_f(r)) {
+      const float x = (lo_b - o) * r, y = (hi_b - o) * r;
+      lo = fminf(x, y);
+      hi = fmaxf(x, y);
+    } else {
+      const float m = 1e-4f * (fabsf(lo_b) + fabsf(hi_b) + fabsf(o)) + 1e-30f;
+      const bool inside = o >= lo_b - m && o <= hi_b + m;
+      lo = inside ? -kInf : kInf;
+      hi = inside ? kInf : -kInf;
+    }
+  };
+  float lx, hx, ly, hy, lz, hz;
+  axis(bmin.x, bmax.x, oo.x, inv.x, lx, hx);
+  axis(bmin.y, bmax.y, oo.y, inv.y, ly, hy);
+  axis(bmin.z, bmax.z, oo.z, inv.z, lz, hz);
+  t_near = fmaxf(fmaxf(lx, ly), lz);
+  t_far = fminf(fminf(hx, hy), hz);
+}
+
 // the reference's test (ray_aabb) that also hands back its two extremes
 __device__ __forceinline__ bool slab_exact(const f3 bmin, const f3 bmax, const f3 o, const f3 d, float& t_near,
                                            float& t_far)
@@ -313,6 +344,7 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
     float tn, tf;
     if (kCount) ++tally.boxes;
     if (!box_pass_inner(ld3(sc.root_min), ld3(sc.root_max), oo, od, inv, exact_only, tn, tf)) return;
+    if (exact_only) slab_cull(ld3(sc.root_min), ld3(sc.root_max), oo, inv, tn, tf);
     if (box_culled(tn, tf, limit)) return;
   }
   const float4* tris = sc.tris + 3u * (size_t)tri_base;
@@ -356,15 +388,26 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
     if (kCount) { tally.boxes += 2u; ++tally.nodes; }
     // Both children through the same code.  An inner child's decision must equal the reference's: the
     // shortcut decides unless the slab extremes are closer than its rounding error (then: exact test).
-    // A leaf child's box is not part of the reference's decision: its triangle is skipped only when the
-    // box is missed by a margin far beyond rounding.
-    float ln, lf, rn, rf;
-    slab_fast(lmin, lmax, oo, inv, ln, lf);
-    slab_fast(rmin, rmax, oo, inv, rn, rf);
+    // A leaf child's box is not part of the reference's decision: its triangle is skipped only when the ray misses
+    // the box by a margin far beyond rounding IN SPACE -- the box is grown by 1e-5 of its coordinates (~100 ulp)
+    // before the test.  (A margin relative to t does not do: 1/d magnifies one ulp of distance from the box to
+    // any t when a direction component is tiny, while the triangle test's own tolerance is relative to the
+    // coordinates; found with direction components of 1e-30.)
     const bool l_leaf = (lref & kLeafBit) != 0u, r_leaf = (rref & kLeafBit) != 0u;
+    auto grow = [&](const f3 lo, const f3 hi, bool leaf) -> f3 {
+      const float k = leaf ? 1e-5f : 0.0f;
+      return mk3(k * (fabsf(lo.x) + fabsf(hi.x) + fabsf(oo.x)) + (leaf ? 1e-30f : 0.0f),
+                 k * (fabsf(lo.y) + fabsf(hi.y) + fabsf(oo.y)) + (leaf ? 1e-30f : 0.0f),
+                 k * (fabsf(lo.z) + fabsf(hi.z) + fabsf(oo.z)) + (leaf ? 1e-30f : 0.0f));
+    };
+    const f3 lm = grow(lmin, lmax, l_leaf), rm = grow(rmin, rmax, r_leaf);
+    const f3 lmin_c = lmin - lm, lmax_c = lmax + lm, rmin_c = rmin - rm, rmax_c = rmax + rm;  // inner: unchanged
+    float ln, lf, rn, rf;
+    slab_fast(lmin_c, lmax_c, oo, inv, ln, lf);
+    slab_fast(rmin_c, rmax_c, oo, inv, rn, rf);
     const float lgap = lf - ln, rgap = rf - rn;
-    const float ltol = (l_leaf ? 1e-4f : 4e-7f) * (fabsf(lf) + fabsf(ln)) + 1e-30f;
-    const float rtol = (r_leaf ? 1e-4f : 4e-7f) * (fabsf(rf) + fabsf(rn)) + 1e-30f;
+    const float ltol = 4e-7f * (fabsf(lf) + fabsf(ln)) + 1e-30f;
+    const float rtol = 4e-7f * (fabsf(rf) + fabsf(rn)) + 1e-30f;
     bool go_l = l_leaf ? !(lgap < -ltol) : (lgap > ltol);
     bool go_r = r_leaf ? !(rgap < -rtol) : (rgap > rtol);
     const bool l_unsure = !l_leaf && (exact_only || !(lgap > ltol || lgap < -ltol));
@@ -373,8 +416,12 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
       if (l_unsure) go_l = slab_exact(lmin, lmax, oo, od, ln, lf);
       if (r_unsure) go_r = slab_exact(rmin, rmax, oo, od, rn, rf);
       if (exact_only) {
+        // a direction component without a finite reciprocal: decisions as above (inner: the reference's own test;
+        // leaf: visit), culling bounds from the form that is safe for such rays
         go_l = go_l || l_leaf;
         go_r = go_r || r_leaf;
+        slab_cull(lmin_c, lmax_c, oo, inv, ln, lf);
+        slab_cull(rmin_c, rmax_c, oo, inv, rn, rf);
       }
     }
     go_l = go_l && !box_culled(ln, lf, limit);

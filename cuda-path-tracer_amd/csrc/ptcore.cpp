@@ -155,6 +155,7 @@ struct ptc_ctx {
   std::vector<hipEvent_t> free_events;
   double trace_ms[kMaxBounces] = {};
   uint32_t trace_launches[kMaxBounces] = {};
+  uint64_t intersect_redone = 0;         // rays ptc_intersect_rays redid exactly (reported as slow_rays[0])
   double denoise_ms = 0.0;               // A-Trous passes (TimedLaunch::bounce == -1)
   uint32_t denoise_passes = 0;
 };
@@ -1202,6 +1203,7 @@ int ptc_reset_profile(ptc_ctx* ctx)
   std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
   ctx->denoise_ms = 0.0;
   ctx->denoise_passes = 0;
+  ctx->intersect_redone = 0;
   const size_t off = offsetof(DeviceCounters, paths), end = offsetof(DeviceCounters, work);
   for (auto& sl : ctx->slots)
     for (int k = 0; k < sl.capacity; ++k)
@@ -1237,6 +1239,7 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
     out->trace_ms[b] = ctx->trace_ms[b];
     out->trace_launches[b] = ctx->trace_launches[b];
   }
+  out->slow_rays[0] += ctx->intersect_redone;
   out->denoise_ms = ctx->denoise_ms;
   out->denoise_passes = ctx->denoise_passes;
   return PTC_OK;
@@ -1334,6 +1337,9 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
     e = hipGetLastError();
   }
   uint32_t dev_flags = 0u;
+  unsigned long long redone = 0ull;
+  if (e == hipSuccess && path_like)
+    e = hipMemcpyAsync(&redone, &counters->slow_rays[0], sizeof redone, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(tp.data(), hits.tp, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(nm.data(), hits.nm, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && path_like)
@@ -1342,6 +1348,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   free_pool(pool);
   if (e != hipSuccess) return fail(ctx, PTC_ERR_HIP, std::string("intersect_rays: ") + hipGetErrorString(e));
   if (dev_flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow in ptc_intersect_rays");
+  ctx->intersect_redone += redone;
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t ms;
     std::memcpy(&ms, &nm[i].w, 4);

@@ -1,5 +1,5 @@
 """Workload for rocprofv3 --pmc passes: N streaming frames of config 3 (1080p, 1M triangles, 8 bounces)."""
-import sys; sys.path.insert(0, '/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4

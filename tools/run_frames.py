@@ -1,6 +1,6 @@
 """N streaming frames of a named scene with a given trace variant (workload for rocprofv3 runs).
 usage: run_frames.py <heightfield|bunny|spheres> <variant> <frames>"""
-import sys; sys.path.insert(0, '/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 which = sys.argv[1]; variant = int(sys.argv[2]); n = int(sys.argv[3])
