@@ -47,11 +47,12 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //           e1 = p1 - p0, e2 = p2 - p0, n = normalize(cross(e1, e2))   (exactly what the reference
 //           recomputes per test, path_tracer.cu:57-59, intersections.cuh:45-46,54-55)
 //   bvh4q: the same tree collapsed to four children per node for the persistent traversal, 64 bytes per node
-//         (half a cache line, four 16-byte loads): dwords 0-2 origin xyz (f32); dword 3 = exponents of the three
-//         power-of-two grid steps (one byte per axis, IEEE biased); dwords 4-9 = child planes as 8-bit grid
+//         (half a cache line, four 16-byte loads): dwords 0-2 origin xyz (f32); dword 3 and dwords 10, 11 = the three
+//         power-of-two grid steps x, y, z as floats; dwords 4-9 = child planes as 8-bit grid
 //         coordinates, component-major (lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4] hi_z[4], child c in byte c), rounded
 //         outwards: a quantised child box contains the exact one, which is all a conservative walk needs;
-//         dwords 12-15 = refs[4].  ref = node index, kLeafBit | depth-first triangle rank, or kNoChild.
+//         dwords 12-15 = refs[4].  ref = node index or kLeafBit | depth-first triangle rank; an unused slot has an
+//         inside-out box (lower planes 255, upper planes 0) and refers to the dummy triangle (DScene::dummy_ref).
 //         Nodes in depth-first preorder.
 //   leaf_parent: per triangle (depth-first rank) the box of the leaf's parent in the REFERENCE tree, 2 float4.
 //         Why it suffices for exactness: boxes nest exactly (parent = componentwise min/max of children) and
@@ -79,6 +80,7 @@ struct DScene {
   uint32_t spill_cap;              // entries per thread in `spill`
   uint32_t lds_cap;                // entries per lane kept in LDS before `spill` (kLds4; fewer only in tests)
   uint32_t bvh4_root;
+  uint32_t dummy_ref;              // reference in the unused child slots of a four-wide node (an inside-out box, a triangle no ray hits)
   uint32_t force_slow;             // test hook: hand EVERY ray to the exact redo (redo_slow_rays)
   uint32_t static_eighths;         // persistent traversal: share (x/8) of each image region dealt without atomics
   uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle

@@ -38,7 +38,8 @@ struct Wide4Accel {
   // power-of-two grid steps | child planes as 8-bit grid coordinates, SoA (lo_x[4] lo_y[4] lo_z[4] hi_x[4] hi_y[4]
   // hi_z[4]), rounded outwards so that every quantised child box contains the exact one | 2 pad | the four child refs
   std::vector<uint32_t> nodes_q;
-  std::vector<float4> leaf_parent;  // 2 per triangle (depth-first leaf order): box of the leaf's parent node
+  std::vector<float4> leaf_parent;  // 2 per triangle (depth-first leaf order): box of the leaf's parent node; + the dummy's
+  uint32_t dummy_ref = 0;           // kLeafBit | triangle count: what the unused child slots of a node point at, see quantise()
   uint32_t root_ref = 0;
   uint32_t depth = 0;               // levels of four-wide nodes above the deepest leaf
   uint32_t node_count = 0;

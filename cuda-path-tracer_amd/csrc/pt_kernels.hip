@@ -835,6 +835,12 @@ struct BatchFeed {
 #ifndef PT_T4_WAVES
 #define PT_T4_WAVES 5
 #endif
+#ifndef PT_FULL_SORT
+#define PT_FULL_SORT 1
+#endif
+#ifndef PT_FLAT_TRI
+#define PT_FLAT_TRI 1
+#endif
 constexpr int kLds4 = PT_T4_LDS;  // traversal stack entries per lane in LDS (6 KiB per wavefront); deeper: DScene::spill
 
 // Set a ray aside for the exact redo at the end of the launch (redo_slow_rays).  The entry is written with an
@@ -1085,8 +1091,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         // axis and node, one fma per plane.  The quantised boxes contain the exact ones, so the walk stays
         // conservative; the exact tests of the winner use the exact parent box (leaf_parent) as before.
         const f3 org = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-        const f3 ax = mk3(__uint_as_float((q0.w & 0xffu) << 23) * inv.x, __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * inv.y,
-                          __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * inv.z);
+        const f3 ax = mk3(__uint_as_float(q0.w) * inv.x, __uint_as_float(q2.z) * inv.y, __uint_as_float(q2.w) * inv.z);
         const f3 bn = mk3(__builtin_fmaf(org.x, inv.x, oin.x), __builtin_fmaf(org.y, inv.y, oin.y), __builtin_fmaf(org.z, inv.z, oin.z));
         const f3 bf = mk3(__builtin_fmaf(org.x, inv.x, oif.x), __builtin_fmaf(org.y, inv.y, oif.y), __builtin_fmaf(org.z, inv.z, oif.z));
         const uint32_t nqx = neg_x ? q1.w : q1.x, fqx = neg_x ? q1.x : q1.w;
@@ -1094,20 +1099,23 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         const uint32_t nqz = neg_z ? q2.y : q1.z, fqz = neg_z ? q1.z : q2.y;
         float key[4];
         uint32_t ref[4] = {q3.x, q3.y, q3.z, q3.w};
+        // tn is a lower bound of the true entry distance and tf an upper bound of the true exit distance (the
+        // tolerance is inside oin / oif), so the child can be skipped when the interval [max(tn, 0), min(tf,
+        // limit)] is empty: box missed, box behind the origin (every t in it < 0 < t_min), or box beyond the
+        // closest hit so far (limit carries a 0.1 % margin; ties at equal t start no farther than the hit).
+        // (An unused slot carries an inside-out box and needs no test of its own, see Collapse::quantise.)
+        // (Measured dead end: the 24 plane FMAs as 12 v_pk_fma_f32 -- clean code, no pair-forming moves -- run 1 %
+        // SLOWER; packed f32 does not issue faster than two plain FMAs on gfx950, MI355X_MICROARCH.md constants table.)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          // tn is a lower bound of the true entry distance and tf an upper bound of the true exit distance (the
-          // tolerance is inside oin / oif), so the child can be skipped when the interval [max(tn, 0), min(tf,
-          // limit)] is empty: box missed, box behind the origin (every t in it < 0 < t_min), or box beyond the
-          // closest hit so far (limit carries a 0.1 % margin; ties at equal t start no farther than the hit).
           const float cnx = (float)((nqx >> (8 * c)) & 0xffu), cny = (float)((nqy >> (8 * c)) & 0xffu), cnz = (float)((nqz >> (8 * c)) & 0xffu);
           const float cfx = (float)((fqx >> (8 * c)) & 0xffu), cfy = (float)((fqy >> (8 * c)) & 0xffu), cfz = (float)((fqz >> (8 * c)) & 0xffu);
           const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(cnx, ax.x, bn.x), __builtin_fmaf(cny, ax.y, bn.y)),
                                        __builtin_fmaf(cnz, ax.z, bn.z)), 0.0f);
           const float tf = fminf(fminf(fminf(__builtin_fmaf(cfx, ax.x, bf.x), __builtin_fmaf(cfy, ax.y, bf.y)),
                                        __builtin_fmaf(cfz, ax.z, bf.z)), limit);
-          if (kCount && ref[c] != kNoChild) { ++tally.boxes; ++ray_boxes; }
-          key[c] = (ref[c] != kNoChild && tn <= tf) ? tn : __builtin_inff();
+          if (kCount && ref[c] != sc.dummy_ref) { ++tally.boxes; ++ray_boxes; }
+          key[c] = tn <= tf ? tn : __builtin_inff();
         }
         // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
         auto cx = [&](int a, int b) {
@@ -1123,7 +1131,9 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         cx(2, 3);
         cx(0, 2);
         cx(1, 3);
+#if PT_FULL_SORT
         cx(1, 2);
+#endif
         // the others go on the stack, farthest first
         if (__builtin_expect(sp + 3 <= lds_cap, 1)) {
           // room for all three in LDS: write unconditionally, advance only past the ones that count (a slot that
@@ -1151,6 +1161,24 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         const f3 p0 = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
         const f3 e1 = mk3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
         const f3 e2 = mk3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+#if PT_FLAT_TRI
+        // the same operations in the same order as the nested form below, evaluated unconditionally (a lane whose
+        // test fails early computes garbage that is never looked at: with a dozen lanes per wavefront in this
+        // branch some lane reaches every stage anyway, so the early outs only cost their branches)
+        const f3 h = cross(rd, e2);
+        const float a = dot(e1, h);
+        const f3 sv = ro - p0;
+        const float f = 1.0f / a;
+        const float u = f * dot(sv, h);
+        const f3 qv = cross(sv, e1);
+        const float w = f * dot(rd, qv);
+        const float t = f * dot(e2, qv);
+        const bool hit = !(a > -0.0000001f && a < 0.0000001f) & !(u < 0.0f || u > 1.0f) & !(w < 0.0f || u + w > 1.0f) &
+                         !(t < tmin) & (t < best_t || (t == best_t && (int)index > best_k));
+        best_t = hit ? t : best_t;
+        best_k = hit ? (int)index : best_k;
+        limit = hit ? scale * t * 1.001f : limit;
+#else
         const f3 h = cross(rd, e2);
         const float a = dot(e1, h);
         const f3 sv = ro - p0;
@@ -1170,6 +1198,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
             }
           }
         }
+#endif
         cur = below;
         sp = sp > 0 ? sp - 1 : 0;
       }

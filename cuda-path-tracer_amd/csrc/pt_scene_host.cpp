@@ -233,7 +233,11 @@ struct Collapse {
         bool ok = true;
         uint32_t lo_q = 0u, hi_q = 0u;
         for (int k = 0; k < 4; ++k) {
-          uint32_t ql = 0u, qh = 0u;
+          // unused slot: an inside-out box (lower planes at the top of the grid, upper planes at its bottom).  Its
+          // slab interval is empty for every ray unless the whole node is smaller than the walk's error bound, and
+          // then the slot's reference leads to the dummy triangle, which no ray hits: the kernel needs no
+          // "is this slot used" test
+          uint32_t ql = 255u, qh = 0u;
           if (k < nk) {
             const double fl = std::floor(((double)lo[a][k] - (double)origin) / step);
             const double ce = std::ceil(((double)hi[a][k] - (double)origin) / step);
@@ -255,8 +259,10 @@ struct Collapse {
       std::memcpy(&q[a], &origin, 4);
       exps |= (uint32_t)(e + 127) << (8 * a);
     }
-    q[3] = exps;
-    q[10] = q[11] = 0u;
+    // the three grid steps as ready-made floats (exponent field only): dword 3 = step x, dwords 10, 11 = step y, z
+    q[3] = (exps & 0xffu) << 23;
+    q[10] = ((exps >> 8) & 0xffu) << 23;
+    q[11] = ((exps >> 16) & 0xffu) << 23;
     for (int k = 0; k < 4; ++k) q[12 + k] = refs[k];
   }
 
@@ -308,7 +314,7 @@ struct Collapse {
         refs[k] = emit(kids[k], level + 1u);
       } else {
         for (int a = 0; a < 3; ++a) lo[a][k] = hi[a][k] = 0.0f;
-        refs[k] = kNoChild;  // unused slot: the kernel skips it by its reference
+        refs[k] = out.dummy_ref;  // unused slot: see quantise()
       }
     }
     quantise(idx, nk, lo, hi, refs);
@@ -352,6 +358,11 @@ int build_wide4(const ptc_bvh_node* nodes, uint32_t count, Wide4Accel& out)
       }
     }
   }
+  // the dummy triangle every unused child slot refers to: rank = triangle count; its record in `tris` is all zeros
+  // (zero edges: the determinant test rejects it), its "parent box" is never looked at
+  out.dummy_ref = kLeafBit | leaves;
+  out.leaf_parent.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+  out.leaf_parent.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
   out.nodes_q.reserve((size_t)count / 2u * 16u);
   // Which reference nodes become four-wide nodes: every triangle is a child of exactly one four-wide node whatever
   // the choice, so the expected cost of a walk differs only by the nodes visited -- minimise the summed surface

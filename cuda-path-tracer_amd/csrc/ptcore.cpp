@@ -471,12 +471,15 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   WideAccel wa;
   if (int rc = build_wide(nodes, node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
   if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
+  // per instance: the mesh's triangles + one all-zero record, the dummy triangle of the four-wide tree's unused
+  // child slots (Wide4Accel::dummy_ref)
+  const size_t inst_tris = wa.tri_order.size() + 1u;
   std::vector<uint32_t> tri_base(s->object_count, 0u);
   size_t mesh_objects = 0;
   for (uint32_t i = 0; i < s->object_count; ++i)
-    if (s->objects[i].type == 1u) tri_base[i] = (uint32_t)(mesh_objects++ * wa.tri_order.size());
-  if (mesh_objects * wa.tri_order.size() > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
-  std::vector<float4> tris(mesh_objects * wa.tri_order.size() * 3u);
+    if (s->objects[i].type == 1u) tri_base[i] = (uint32_t)(mesh_objects++ * inst_tris);
+  if (mesh_objects * inst_tris > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
+  std::vector<float4> tris(mesh_objects * inst_tris * 3u);
   for (uint32_t i = 0; i < s->object_count; ++i) {
     if (s->objects[i].type != 1u || wa.tri_order.empty()) continue;
     m4 m;
@@ -494,6 +497,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     d.bvh4q = reinterpret_cast<const uint4*>(q);
   }
   d.bvh4_root = w4.root_ref;
+  d.dummy_ref = w4.dummy_ref;
   d.refill_lanes = ctx->refill_lanes;
   d.static_eighths = ctx->static_eighths;
   d.force_slow = (uint32_t)ctx->force_slow;
@@ -1426,7 +1430,11 @@ int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, u
       bool any = false;
       for (int c = 0; c < 4; ++c) {
         const uint32_t ref = q[12 + c];
-        if (ref == pt::kNoChild) continue;
+        if (ref == w4.dummy_ref) {  // unused slot: must carry the inside-out box on every axis
+          for (int ax = 0; ax < 3; ++ax)
+            if (((q[4 + ax] >> (8 * c)) & 0xffu) != 255u || ((q[7 + ax] >> (8 * c)) & 0xffu) != 0u) ++bad;
+          continue;
+        }
         uint32_t a, b;
         if (ref & pt::kLeafBit) {
           a = b = ref & ~pt::kLeafBit;
@@ -1449,7 +1457,7 @@ int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, u
       std::memcpy(origin, q, 12);
       for (int c = 0; c < 4; ++c) {
         const uint32_t ref = q[12 + c];
-        if (ref == pt::kNoChild) continue;
+        if (ref == w4.dummy_ref) continue;
         uint32_t a, b;
         if (ref & pt::kLeafBit) {
           a = b = ref & ~pt::kLeafBit;
@@ -1465,7 +1473,9 @@ int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, u
         }
         const ptc_bvh_node& x = nodes[it->second];
         for (int ax = 0; ax < 3; ++ax) {
-          const double step = std::ldexp(1.0, (int)((q[3] >> (8 * ax)) & 0xffu) - 127);
+          const uint32_t step_bits = q[ax == 0 ? 3 : 9 + ax];
+          if (step_bits & 0x807fffffu) ++bad;  // a power of two
+          const double step = std::ldexp(1.0, (int)(step_bits >> 23) - 127);
           const double lo = (double)origin[ax] + (double)((q[4 + ax] >> (8 * c)) & 0xffu) * step;
           const double hi = (double)origin[ax] + (double)((q[7 + ax] >> (8 * c)) & 0xffu) * step;
           if (lo > (double)x.aabb_min[ax] || hi < (double)x.aabb_max[ax]) ++bad;
