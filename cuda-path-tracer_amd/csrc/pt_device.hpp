@@ -189,19 +189,25 @@ void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DB
                    DPaths paths, DeviceCounters* counters);
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
-                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests, int variant);
-// variant 3 (default): per bounce, the objects are walked in the reference's order as a sequence of segments:
-//   launch_spheres  objects [obj_begin, obj_end), all spheres; carries the closest hit so far in the hit record
-//                   (first: nothing to read; last: also emits the per-chunk live counts for the compaction scan)
-//   launch_traverse one mesh object: persistent wavefronts, each lane fetches the next ray when its own is done;
-//                   rays it sets aside (degenerate direction, winner grazing its parent box) are redone exactly by
-//                   the last wavefront of the same launch
-void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
-                    DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
-                    DeviceCounters* counters, const DBatchInfo& bi);
+                  DeviceCounters* counters, bool count_tests, int variant);
+// variant 3 (default): per bounce, the object list is walked in the reference's order; the closest hit so far
+// travels from launch to launch in the hit record:
+//   launch_traverse   one mesh object: persistent wavefronts, each lane fetches the next ray when its own is done;
+//                     rays it sets aside (degenerate direction, winner grazing its parent box) are redone exactly by
+//                     the last wavefront of the same launch
+//   launch_spheres    a run of spheres in FRONT of a mesh (objects [obj_begin, obj_end))
+//   launch_tail_count the end of the stage: the run of spheres that ends the object list (may be empty, may be the
+//                     whole list) and the live count of every 64-slot chunk from the hit records; also after launch_trace
+//   launch_scan       exclusive scan of those counts (compaction offsets, live[bounce + 1])
+// first: nothing has written the hit records in this bounce yet
+void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
+                    uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                      uint32_t* slow_list, const DBatchInfo& bi);
+void launch_tail_count(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
+                       DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts, DeviceCounters* counters,
+                       const DBatchInfo& bi);
 void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
                  DeviceCounters* counters, const DBatchInfo& bi);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

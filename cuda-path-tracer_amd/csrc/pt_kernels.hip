@@ -645,11 +645,9 @@ __device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
   return r;
 }
 
-// intersection_kernel, path_tracer.cu:271-290.  One wavefront per 64-path chunk; also produces the
-// chunk's live count for the compaction scan.
+// intersection_kernel, path_tracer.cu:271-290.  One wavefront per 64-path chunk.
 template <bool kCount>
-__global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits hits, int bounce, uint32_t* chunk_counts,
-                                                 DeviceCounters* counters)
+__global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits hits, int bounce, DeviceCounters* counters)
 {
   __shared__ uint32_t s_stack[kStackDepth * kWave];
   const uint32_t n = counters->live[bounce];
@@ -670,8 +668,6 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
     hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
     if (flags) atomicOr(&counters->flags, flags);
   }
-  const uint64_t live = __ballot(hit);
-  if (threadIdx.x == 0u) chunk_counts[blockIdx.x] = (uint32_t)__popcll(live);
   if (kCount) flush_tally(tally, counters, bounce, true);
 }
 
@@ -680,8 +676,7 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
 // chunks = one contiguous image region: neighbouring paths walk the same subtrees, which keeps that
 // XCD's 4 MiB L2 on one part of the BVH.  Placement only affects speed.
 template <bool kCount>
-__global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, DHits hits, int bounce,
-                                                      uint32_t* chunk_counts, DeviceCounters* counters)
+__global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, DHits hits, int bounce, DeviceCounters* counters)
 {
   __shared__ uint32_t s_stack[kWideStack * kWave];
   const uint32_t n = counters->live[bounce];
@@ -705,9 +700,61 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
     hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
     if (flags) atomicOr(&counters->flags, flags);
   }
-  const uint64_t live = __ballot(hit);
-  if (threadIdx.x == 0u) chunk_counts[chunk] = (uint32_t)__popcll(live);
   if (kCount) flush_tally(tally, counters, bounce, true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sphere segments
+// ------------------------------------------------------------------------------------------------
+// Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test, path_tracer.cu:78-100)
+// for one ray whose closest hit so far is ray.tmax (FLT_MAX: none).  A sphere that is hit replaces `rec`, shrinks
+// ray.tmax and sets `changed`.  Used by k_spheres (a run in front of a mesh, a scene without a mesh) and by
+// k_count_scan (the run behind the last mesh).
+__device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_begin, uint32_t obj_end, Ray& ray, Hit& rec,
+                                               bool& changed)
+{
+  // 1/d by the hardware reciprocal: decides the world-box test of almost every ray without the reference's six
+  // divisions per object (below)
+  const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+  const bool winv_ok = finite_f(winv.x + winv.y + winv.z);
+  for (uint32_t i = obj_begin; i < obj_end; ++i) {
+    const DObject* obj = sc.objects + i;
+    if (obj->type != 0u) continue;
+    {
+      // ray_aabb_intersection_test (intersections.cuh:87-103) decides by the sign of min(far) - max(near).  With
+      // reciprocals each slab value is within 3 ulp of the reference's quotient, so a gap beyond 2e-6 of the two
+      // extremes has the reference's sign; only a ray that grazes the box within that margin (or has a zero /
+      // non-finite direction component) takes the divisions.
+      const f3 bmin = ld3(obj->bmin), bmax = ld3(obj->bmax);
+      const f3 a0 = (bmin - ray.o) * winv, a1 = (bmax - ray.o) * winv;
+      const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+      const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+      const float gap = wf - wn, margin = 2e-6f * (fabsf(wf) + fabsf(wn)) + 1e-30f;
+      const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
+      bool pass = gap > margin;
+      const bool unsure = !box_ok || !winv_ok || !(gap > margin || gap < -margin);
+      if (__builtin_expect(unsure, 0)) pass = ray_aabb(ray.o, ray.d, bmin, bmax);
+      if (!pass) continue;
+    }
+    Ray tr;
+    inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
+    tr.tmin = ray.tmin;
+    tr.tmax = ray.tmax;
+    const float4 sp = sc.spheres[obj->index];
+    if (ray_sphere(tr, xyz(sp), sp.w, rec)) {
+      rec.p = xform_point(obj->m, rec.p);
+      rec.t = length(rec.p - ray.o);
+      rec.n = xform_normal(obj->inv_m, rec.n);
+      rec.mat = sc.object_material[i];
+      ray.tmax = rec.t;
+      changed = true;
+    }
+  }
+}
+__device__ __forceinline__ void store_hit(const DHits& hits, uint32_t slot, const Hit& rec)
+{
+  hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
+  hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1281,11 +1328,44 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   }
 }
 
-// Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test,
-// path_tracer.cu:78-100), continuing from / handing on the closest hit in the hit record.
-template <bool kFirst, bool kLast>
+// A run of sphere objects that does not end the object list (the spheres in front of a mesh), continuing from /
+// handing on the closest hit in the hit record.  (The run that ENDS the list -- or is the whole list -- is part of
+// k_count_scan.)  (Taking the sphere runs into the traversal kernel instead was tried in round 2: inlined or as a
+// call, their temporaries pushed loop-carried state of the walk into scratch, with reloads inside its hot loop.)
+template <bool kFirst>
 __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
-                                                 int bounce, uint32_t* chunk_counts, DeviceCounters* counters, DBatchInfo bi)
+                                                 int bounce, DeviceCounters* counters, DBatchInfo bi)
+{
+  const uint32_t frame = blockIdx.y;  // see DBatchInfo
+  paths.o4 += (size_t)frame * bi.stride;
+  paths.d4 += (size_t)frame * bi.stride;
+  hits.tp += (size_t)frame * bi.stride;
+  hits.nm += (size_t)frame * bi.stride;
+  counters += frame;
+  const uint32_t n = counters->live[bounce];
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= n) return;
+  Ray ray = load_ray(paths, s);
+  if (!kFirst) {
+    const float carried = hits.tp[s].x;
+    if (carried >= 0.0f) ray.tmax = carried;
+  }
+  Hit rec;
+  bool changed = false;
+  sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
+  if (changed) store_hit(hits, s, rec);
+  else if (kFirst) hits.tp[s] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+}
+
+// The end of a bounce's closest-hit stage: the sphere run that ends the object list (if any) and the live count of
+// every 64-slot chunk (ballot / popcount of "the hit record holds a hit"), for the compaction scan.
+// kSpheres: objects [obj_begin, obj_end) are tested; kFirst: nothing has written the hit record in this bounce yet.
+// 256-thread workgroups: one wavefront per SIMD fits beside the other stream's persistent traversal wavefronts as soon
+// as one of those has left (1024-thread workgroups wait until four per SIMD have: measured 15 % slower end to end,
+// together with a scan fused in behind a "last workgroup" sign-off).
+template <bool kSpheres, bool kFirst>
+__global__ __launch_bounds__(256) void k_tail_count(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
+                                                    int bounce, uint32_t* chunk_counts, DeviceCounters* counters, DBatchInfo bi)
 {
   const uint32_t frame = blockIdx.y;  // see DBatchInfo
   paths.o4 += (size_t)frame * bi.stride;
@@ -1296,72 +1376,30 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   counters += frame;
   const uint32_t n = counters->live[bounce];
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (blockIdx.x * 256u >= n) return;
+  // a wavefront beyond the live range owns no chunk: k_scan reads ceil(n / 64) entries, and in a batch the next
+  // entries belong to the next frame
+  if ((s & ~63u) >= n) return;
   bool hit = false;
   if (s < n) {
-    Ray ray = load_ray(paths, s);
-    Hit rec;
-    rec.t = -1.0f;
-    rec.p = rec.n = mk3(0.f, 0.f, 0.f);
-    rec.mat = 0u;
-    rec.side = 0u;
-    bool changed = kFirst;
-    if (!kFirst) {
-      const float carried = hits.tp[s].x;
-      if (carried >= 0.0f) {
+    float t_so_far = -1.0f;
+    if (!kFirst) t_so_far = hits.tp[s].x;
+    hit = t_so_far >= 0.0f;
+    if (kSpheres) {
+      Ray ray = load_ray(paths, s);
+      if (hit) ray.tmax = t_so_far;
+      Hit rec;
+      bool changed = false;
+      sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
+      if (changed) {
+        store_hit(hits, s, rec);
         hit = true;
-        ray.tmax = carried;
+      } else if (kFirst) {
+        hits.tp[s] = make_float4(-1.0f, 0.f, 0.f, 0.f);
       }
-    }
-    // 1/d by the hardware reciprocal: decides the world-box test of almost every ray without the reference's six
-    // divisions per object (below)
-    const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
-    const bool winv_ok = finite_f(winv.x + winv.y + winv.z);
-    for (uint32_t i = obj_begin; i < obj_end; ++i) {
-      const DObject* obj = sc.objects + i;
-      if (obj->type != 0u) continue;
-      {
-        // ray_aabb_intersection_test (intersections.cuh:87-103) decides by the sign of min(far) - max(near).  With
-        // reciprocals each slab value is within 3 ulp of the reference's quotient, so a gap beyond 2e-6 of the two
-        // extremes has the reference's sign; only a ray that grazes the box within that margin (or has a zero /
-        // non-finite direction component) takes the divisions.
-        const f3 bmin = ld3(obj->bmin), bmax = ld3(obj->bmax);
-        const f3 a0 = (bmin - ray.o) * winv, a1 = (bmax - ray.o) * winv;
-        const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
-        const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
-        const float gap = wf - wn, margin = 2e-6f * (fabsf(wf) + fabsf(wn)) + 1e-30f;
-        const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
-        bool pass = gap > margin;
-        const bool unsure = !box_ok || !winv_ok || !(gap > margin || gap < -margin);
-        if (__builtin_expect(unsure, 0)) pass = ray_aabb(ray.o, ray.d, bmin, bmax);
-        if (!pass) continue;
-      }
-      Ray tr;
-      inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
-      tr.tmin = ray.tmin;
-      tr.tmax = ray.tmax;
-      const float4 sp = sc.spheres[obj->index];
-      if (ray_sphere(tr, xyz(sp), sp.w, rec)) {
-        rec.p = xform_point(obj->m, rec.p);
-        rec.t = length(rec.p - ray.o);
-        rec.n = xform_normal(obj->inv_m, rec.n);
-        rec.mat = sc.object_material[i];
-        ray.tmax = rec.t;
-        hit = true;
-        changed = true;
-      }
-    }
-    if (changed) {
-      hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
-      hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
     }
   }
-  if (kLast) {
-    const uint64_t live = __ballot(hit);
-    // a wavefront beyond the live range (s >= n) owns no chunk: k_scan reads ceil(n / 64) entries, and in a batch
-    // the next entries belong to the next frame
-    if ((threadIdx.x & 63u) == 0u && s < n) chunk_counts[s / kChunk] = (uint32_t)__popcll(live);
-  }
+  const uint64_t live = __ballot(hit);
+  if ((threadIdx.x & 63u) == 0u) chunk_counts[s / kChunk] = (uint32_t)__popcll(live);
 }
 
 // Exclusive scan of the per-chunk live counts (one workgroup; <= ~32k chunks at 1080p).
@@ -1738,36 +1776,42 @@ void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DB
                      paths, counters);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
-                  uint32_t* chunk_counts, DeviceCounters* counters, bool count_tests, int variant)
+                  DeviceCounters* counters, bool count_tests, int variant)
 {
   if (variant == 1) {
     const dim3 grid(div_up(max_paths, kWave) + 8u);  // room for the per-XCD rounding of the chunk deal
-    if (count_tests)
-      hipLaunchKernelGGL(k_trace_wide<true>, grid, dim3(kWave), 0, s, scene, paths, hits, bounce, chunk_counts, counters);
-    else
-      hipLaunchKernelGGL(k_trace_wide<false>, grid, dim3(kWave), 0, s, scene, paths, hits, bounce, chunk_counts, counters);
+    if (count_tests) hipLaunchKernelGGL(k_trace_wide<true>, grid, dim3(kWave), 0, s, scene, paths, hits, bounce, counters);
+    else hipLaunchKernelGGL(k_trace_wide<false>, grid, dim3(kWave), 0, s, scene, paths, hits, bounce, counters);
     return;
   }
-  if (count_tests)
-    hipLaunchKernelGGL(k_trace<true>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
-                       chunk_counts, counters);
-  else
-    hipLaunchKernelGGL(k_trace<false>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce,
-                       chunk_counts, counters);
+  if (count_tests) hipLaunchKernelGGL(k_trace<true>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce, counters);
+  else hipLaunchKernelGGL(k_trace<false>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce, counters);
 }
-void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, bool last,
-                    DPaths paths, DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts,
-                    DeviceCounters* counters, const DBatchInfo& bi)
+void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
+                    uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi)
 {
   const dim3 grid(div_up(max_paths, 256u), bi.count), block(256);
-  if (first && last)
-    hipLaunchKernelGGL((k_spheres<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
-  else if (first)
-    hipLaunchKernelGGL((k_spheres<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
-  else if (last)
-    hipLaunchKernelGGL((k_spheres<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
-  else
-    hipLaunchKernelGGL((k_spheres<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
+  if (first) hipLaunchKernelGGL((k_spheres<true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi);
+  else hipLaunchKernelGGL((k_spheres<false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi);
+}
+void launch_tail_count(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
+                       DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts, DeviceCounters* counters,
+                       const DBatchInfo& bi)
+{
+  const dim3 grid(div_up(max_paths, 256u), bi.count), block(256);
+  if (obj_begin < obj_end) {
+    if (first) hipLaunchKernelGGL((k_tail_count<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
+    else hipLaunchKernelGGL((k_tail_count<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, chunk_counts, counters, bi);
+  } else {
+    // (nothing to test: some closest-hit launch has written every record of the bounce)
+    hipLaunchKernelGGL((k_tail_count<false, false>), grid, block, 0, s, scene, 0u, 0u, paths, hits, bounce, chunk_counts, counters, bi);
+  }
+}
+void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
+                 DeviceCounters* counters, const DBatchInfo& bi)
+{
+  hipLaunchKernelGGL(k_scan, dim3(bi.count), dim3(1024), 0, s, bounce, last_bounce ? 1 : 0, chunk_counts, chunk_offsets,
+                     counters, bi);
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
@@ -1781,12 +1825,6 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
     if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
     else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
   }
-}
-void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* chunk_counts, uint32_t* chunk_offsets,
-                 DeviceCounters* counters, const DBatchInfo& bi)
-{
-  hipLaunchKernelGGL(k_scan, dim3(bi.count), dim3(1024), 0, s, bounce, last_bounce ? 1 : 0, chunk_counts, chunk_offsets,
-                     counters, bi);
 }
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
                   bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,

@@ -132,11 +132,14 @@ struct ptc_ctx {
   uint64_t frames = 0;
 
   int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse, conservative FMA slabs, exact check of the winner (default); 0: reference-order traversal; 1: culled near-first traversal with exact box decisions
-  struct Segment {
-    bool mesh;
-    uint32_t begin, end;  // object range (mesh: one object)
+  // The closest-hit stage of the default variant, in object order: per mesh object a k_spheres launch for the run of
+  // spheres in front of it ([pre_begin, pre_end), if it holds any) and a persistent traversal launch; the run that
+  // ends the object list ([tail_begin, tail_end): everything, in a scene without a mesh) is part of k_count_scan.
+  struct TraceLaunch {
+    uint32_t mesh, pre_begin, pre_end;
   };
-  std::vector<Segment> segments;  // the object list as alternating sphere runs / single meshes
+  std::vector<TraceLaunch> launches;
+  uint32_t tail_begin = 0, tail_end = 0;
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
@@ -242,6 +245,7 @@ int validate_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (s->sphere_count && !s->spheres) return fail(ctx, PTC_ERR_INVALID, "spheres missing");
   if (s->material_count && !s->materials) return fail(ctx, PTC_ERR_INVALID, "materials missing");
   if (s->index_count % 3u) return fail(ctx, PTC_ERR_INVALID, "index_count is not a multiple of 3");
+  if (s->object_count > 0xffffu) return fail(ctx, PTC_ERR_INVALID, "more than 65535 objects");
   if (s->index_count && (!s->indices || !s->positions)) return fail(ctx, PTC_ERR_INVALID, "mesh arrays missing");
   for (uint32_t i = 0; i < s->index_count; ++i)
     if (s->indices[i] >= s->vertex_count) return fail(ctx, PTC_ERR_INVALID, "vertex index out of range");
@@ -515,20 +519,26 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.root_ref = wa.root_ref;
   d.object_count = s->object_count;
   d.bvh_node_count = node_count;
-  // segments for the persistent pipeline: runs of spheres and single mesh objects, in object order
-  ctx->segments.clear();
-  for (uint32_t i = 0; i < s->object_count;) {
-    if (s->objects[i].type == 1u) {
-      if (node_count) ctx->segments.push_back({true, i, i + 1u});
-      ++i;
-    } else {
-      uint32_t j = i;
-      while (j < s->object_count && s->objects[j].type == 0u) ++j;
-      ctx->segments.push_back({false, i, j});
-      i = j;
-    }
+  // launches of the persistent pipeline (TraceLaunch).  A mesh object without nodes (empty mesh) is no launch; the
+  // sphere code skips non-sphere objects, so the runs on both sides of it merge.
+  ctx->launches.clear();
+  {
+    auto has_sphere = [&](uint32_t b, uint32_t e) {
+      for (uint32_t i = b; i < e; ++i)
+        if (s->objects[i].type == 0u) return true;
+      return false;
+    };
+    uint32_t run_begin = 0;  // objects [run_begin, i) hold the spheres seen since the last mesh launch
+    for (uint32_t i = 0; i < s->object_count; ++i)
+      if (s->objects[i].type == 1u && node_count) {
+        const bool any = has_sphere(run_begin, i);
+        ctx->launches.push_back({i, any ? run_begin : 0u, any ? i : 0u});
+        run_begin = i + 1u;
+      }
+    const bool any = has_sphere(run_begin, s->object_count);
+    ctx->tail_begin = any ? run_begin : 0u;
+    ctx->tail_end = any ? s->object_count : 0u;
   }
-  if (ctx->segments.empty() || ctx->segments.back().mesh) ctx->segments.push_back({false, s->object_count, s->object_count});
   ctx->scene = d;
   ctx->has_scene = true;
   ctx->bvh_nodes = node_count;
@@ -849,39 +859,43 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     ctx->timed.push_back(tl);
     return PTC_OK;
   };
+  bool wrote = false;  // some launch of this bounce has written the hit records
   if (ctx->trace_variant == 3) {
-    // closest hit = the object list walked as segments (see launch_spheres / launch_traverse)
-    for (size_t k = 0; k < ctx->segments.size(); ++k) {
-      const auto& seg = ctx->segments[k];
-      const bool first = k == 0, final_seg = k + 1 == ctx->segments.size();
-      if (seg.mesh) {
-        if (sl.work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
-          for (uint32_t fr = 0; fr < sl.bi.count; ++fr)
-            HIP_TRY(ctx, hipMemsetAsync(&sl.counters[fr].work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, sl.stream));
-          sl.work_slot = 0;
-        }
-        ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
-        if (int rc = timed_begin(tl)) return rc;
-        // persistent wavefronts for this launch: about 48 ray batches of 64 per wavefront at the first bounce (a
-        // wavefront that gets only a few batches spends its life draining), at least 1024, at most the
-        // configured number (what is resident; the stack overflow areas are sized for it)
-        const uint64_t rays0 = (uint64_t)sl.bi.count * ctx->pix_count;
-        const uint32_t waves = (uint32_t)std::min<uint64_t>(ctx->traverse_waves, std::max<uint64_t>(1024u, (rays0 / 3072u + 7u) & ~7ull));
-        launch_traverse(sl.stream, scene, seg.begin, first, in, sl.hits, bounce, sl.work_slot++, sl.counters,
-                        ctx->count_tests, waves, sl.slow_list, sl.bi);
-        if (int rc = timed_end(tl)) return rc;
-      } else {
-        launch_spheres(sl.stream, scene, seg.begin, seg.end, first, final_seg, in, sl.hits, ctx->pix_count, bounce,
-                       sl.chunk_counts, sl.counters, sl.bi);
+    // closest hit = the object list walked by the launches of TraceLaunch
+    for (size_t k = 0; k < ctx->launches.size(); ++k) {
+      const auto& l = ctx->launches[k];
+      if (l.pre_begin < l.pre_end) {
+        launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi);
+        wrote = true;
       }
+      if (sl.work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
+        for (uint32_t fr = 0; fr < sl.bi.count; ++fr)
+          HIP_TRY(ctx, hipMemsetAsync(&sl.counters[fr].work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, sl.stream));
+        sl.work_slot = 0;
+      }
+      ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
+      if (int rc = timed_begin(tl)) return rc;
+      // persistent wavefronts for this launch: about 48 ray batches of 64 per wavefront at the first bounce (a
+      // wavefront that gets only a few batches spends its life draining), at least 1024, at most the
+      // configured number (what is resident; the stack overflow areas are sized for it)
+      const uint64_t rays0 = (uint64_t)sl.bi.count * ctx->pix_count;
+      const uint32_t waves = (uint32_t)std::min<uint64_t>(ctx->traverse_waves, std::max<uint64_t>(1024u, (rays0 / 3072u + 7u) & ~7ull));
+      launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
+                      sl.slow_list, sl.bi);
+      wrote = true;
+      if (int rc = timed_end(tl)) return rc;
     }
   } else {
     ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
     if (int rc = timed_begin(tl)) return rc;
-    launch_trace(sl.stream, scene, in, sl.hits, ctx->pix_count, bounce, sl.chunk_counts, sl.counters,
-                 ctx->count_tests, ctx->trace_variant);
+    launch_trace(sl.stream, scene, in, sl.hits, ctx->pix_count, bounce, sl.counters, ctx->count_tests, ctx->trace_variant);
+    wrote = true;
     if (int rc = timed_end(tl)) return rc;
   }
+  // the sphere run that ends the object list (variant 3 only) + the live counts; their scan
+  const bool tail = ctx->trace_variant == 3 && ctx->tail_begin < ctx->tail_end;
+  launch_tail_count(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, sl.hits, ctx->pix_count,
+                    bounce, sl.chunk_counts, sl.counters, sl.bi);
   launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
   launch_shade(sl.stream, scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
                sl.chunk_offsets, sl.stage, ctx->band, sl.counters, sl.bi);
@@ -1258,8 +1272,9 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   if (n > 0x7fffffffu) return fail(ctx, PTC_ERR_INVALID, "too many rays");
   if (int rc = bind_device(ctx)) return rc;
   if (int rc = flush_pending(ctx)) return rc;
-  // The default schedule (variant 3) is the production closest-hit stage itself: the object list walked as sphere /
-  // mesh segments (k_spheres, k_traverse4 and its exact redo), fed with the caller's rays instead of path state.
+  // The default schedule (variant 3) is the production closest-hit stage itself: the object list walked by the
+  // traversal launches (k_traverse4 with its sphere runs and its exact redo), fed with the caller's rays instead of
+  // path state.
   // Path rays know two t_min values (1e-4, and 1e-5 after a dielectric: a flag bit) and start every bounce with
   // t_max = FLT_MAX; a caller's t_max enters as the "closest hit so far" the segments carry in the hit record.
   // Rays with another t_min take the one-wavefront-per-64-rays kernel with exact box decisions (variant 1).
@@ -1326,14 +1341,13 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
       bi.count = 1u;
       const uint32_t waves = std::min<uint32_t>(ctx->traverse_waves, std::max<uint32_t>(8u, ((n / (4u * kWave)) + 7u) & ~7u));
       int work_slot = 0;
-      for (size_t k = 0; k < ctx->segments.size() && work_slot < kWorkSlots; ++k) {
-        const auto& seg = ctx->segments[k];
-        if (seg.mesh)
-          launch_traverse(ctx->stream, scene, seg.begin, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, bi);
-        else
-          launch_spheres(ctx->stream, scene, seg.begin, seg.end, false, k + 1 == ctx->segments.size(), paths, hits, n, 0,
-                         chunk_counts, counters, bi);
+      for (size_t k = 0; k < ctx->launches.size() && work_slot < kWorkSlots; ++k) {
+        const auto& l = ctx->launches[k];
+        if (l.pre_begin < l.pre_end)
+          launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
+        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, bi);
       }
+      launch_tail_count(ctx->stream, scene, ctx->tail_begin, ctx->tail_end, false, paths, hits, n, 0, chunk_counts, counters, bi);
       e = hipGetLastError();
     }
   } else if (e == hipSuccess) {
