@@ -28,11 +28,11 @@ Prints ONE JSON line on rank 0 with the contract fields plus:
                 layout-independent minimums taken from the reference's node / triangle sizes), with the counts from
                 an instrumented, untimed re-run of the same frames.  `requested` prices what THIS layout asks the
                 memory system for (64-byte four-child node records, 48-byte triangle records).  `traffic` = HBM-side
-                bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json), given only when
+                bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic_<frames per launch>.json), given only when
                 that record was taken on the same launch shape (frames per launch), else null.  The kernel is not
                 HBM-bound -- its working set lives in L2 / Infinity Cache -- so `valu` carries the roofline that
                 does bind it: VALU issue (busy %, lanes per instruction, instructions per ray; SQ counter passes,
-                profiles/pmc_sq.json).
+                profiles/pmc_sq_<frames per launch>.json).
   parity        GPU iteration 0 of the benchmark scene against the CPU oracle's frame (the one rendered for
                 cpu_baseline): mse, bit_exact, live counts and ray count equal.
   steady_state  the same workload with 32 frames per launch and 256 steps (the tuned schedule; the timed region
@@ -89,7 +89,9 @@ def parse():
 
 def pmc_record(name, frames_per_launch):
     """profiles/<name>: counter figures of the dominant kernel from separate rocprofv3 --pmc passes."""
-    path = os.path.join(ROOT, "profiles", name)
+    path = os.path.join(ROOT, "profiles", name % frames_per_launch)
+    if not os.path.exists(path):   # no record for this launch shape: the 32-frame record, marked as not matching
+        path = os.path.join(ROOT, "profiles", name % 32)
     if not os.path.exists(path):
         return None
     try:
@@ -112,14 +114,14 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
     trace_ms = sum(prof["trace_ms"])
     launches = sum(prof["trace_launches"])
     achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    traffic_rec = pmc_record("pmc_traffic.json", frames_per_launch)
+    traffic_rec = pmc_record("pmc_traffic_%d.json", frames_per_launch)
     traffic = note = None
     if traffic_rec is not None:
         if traffic_rec["matches_this_run"]:
             traffic = traffic_rec.get("trace_kernel_hbm_bytes_per_launch")
-            note = "profiles/pmc_traffic.json (%s)" % traffic_rec.get("source", "separate --pmc passes")
+            note = "profiles/pmc_traffic_<frames per launch>.json (%s)" % traffic_rec.get("source", "separate --pmc passes")
         else:
-            note = ("null: profiles/pmc_traffic.json was measured on %s-frame launches (%.3g GB per launch), this run used %d"
+            note = ("null: the PMC record at hand was measured on %s-frame launches (%.3g GB per launch), this run used %d"
                     % (traffic_rec.get("frames_per_launch"), (traffic_rec.get("trace_kernel_hbm_bytes_per_launch") or 0) / 1e9,
                        frames_per_launch))
     roof = {
@@ -141,10 +143,11 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
         "note": "the kernel's working set (27 MB of nodes + 48 MB of triangles + path state of the batch) is served "
                 "by L2 / Infinity Cache; it is bound by VALU issue at about half lane utilisation, see valu",
     }
-    sq = pmc_record("pmc_sq.json", frames_per_launch)
+    sq = pmc_record("pmc_sq_%d.json", frames_per_launch)
     if sq is not None:
         roof["valu"] = {k: sq.get(k) for k in ("valu_busy_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
-                                                "l2_hit_frac", "frames_per_launch", "source")}
+                                                "salu_inst_per_ray", "l2_hit_frac", "wave_occupancy_frac", "frames_per_launch",
+                                                "matches_this_run", "source")}
     return roof
 
 
