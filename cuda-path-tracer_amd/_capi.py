@@ -65,6 +65,11 @@ class ptc_denoiser_params(C.Structure):
                 ("position_weight", C.c_float)]
 
 
+class ptc_band_handle(C.Structure):
+    _fields_ = [("ipc_mem", C.c_uint8 * 64), ("pix_count", C.c_uint32), ("pix_begin", C.c_uint32), ("width", C.c_uint32),
+                ("rank", C.c_uint32), ("nranks", C.c_uint32), ("block_rows", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
 class ptc_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_bounces", C.c_int32), ("method", C.c_int32), ("reserved", C.c_int32)]
 
@@ -117,6 +122,11 @@ SIGNATURES = {
     "ptc_denoise": (C.c_int, [_P]),
     "ptc_present_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ptc_download": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "ptc_band_export": (C.c_int, [_P, C.POINTER(ptc_band_handle)]),
+    "ptc_band_import": (C.c_int, [_P, C.c_uint32, C.POINTER(ptc_band_handle)]),
+    "ptc_band_publish": (C.c_int, [_P, C.c_int]),
+    "ptc_gather_frame": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "ptc_gather_present_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "ptc_synchronize": (C.c_int, [_P]),
     "ptc_get_stats": (C.c_int, [_P, C.POINTER(ptc_stats)]),
     "ptc_set_profiling": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -47,12 +47,19 @@ def assemble(bands):
 
 
 class BandRenderer:
-    """One rank's band of the frame.  `dist` is torch.distributed (initialised) or None for a single rank."""
+    """One rank's band of the frame.  `dist` is torch.distributed (initialised) or None for a single rank.
 
-    def __init__(self, path_tracer, width, height, rank=0, world=1, dist=None, mode="local"):
-        assert mode in ("local", "global")
+    mode "global", exchange "device": the live count stays on the GPU -- ptc_copy_live_count into a torch tensor,
+    all_gather over RCCL on torch's current stream, exclusive prefix, ptc_trace_bounce reads it from device memory; the
+    library orders its frame stream against torch's stream with events (no host synchronisation; needs the context on
+    torch's current stream, which this class arranges).  exchange "host": the count is read back and gathered as a
+    Python object (any backend, e.g. gloo on a box without RCCL peers) -- the reference's own per-bounce host
+    round trip (path_tracer.cu:457)."""
+
+    def __init__(self, path_tracer, width, height, rank=0, world=1, dist=None, mode="local", exchange="device"):
+        assert mode in ("local", "global") and exchange in ("device", "host")
         self.pt, self.width, self.height = path_tracer, width, height
-        self.rank, self.world, self.dist, self.mode = rank, world, dist, mode
+        self.rank, self.world, self.dist, self.mode, self.exchange = rank, world, dist, mode, exchange
         self.rows = split_rows(height, world)[rank]
         if world > 1:
             self.pt.set_rows(*self.rows)
@@ -60,6 +67,7 @@ class BandRenderer:
         if mode == "global" and world > 1:
             import torch
             self._torch = torch
+            self.pt.set_stream(torch.cuda.current_stream().cuda_stream)
             self._mine = torch.zeros(1, dtype=torch.int32, device="cuda")
             self._all = torch.zeros(world, dtype=torch.int32, device="cuda")
             self._base = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -73,8 +81,40 @@ class BandRenderer:
         self.pt.trace_begin(camera)
         for b in range(self.pt.max_bounces):
             # live count of this band entering bounce b -> all ranks -> exclusive prefix = slot base
-            self.pt.copy_live_count(b, self._mine.data_ptr())
-            self.dist.all_gather_into_tensor(self._all, self._mine)
-            self._base.copy_(self._all[: self.rank].sum().to(torch.int32).reshape(1) if self.rank else torch.zeros(1, dtype=torch.int32, device="cuda"))
+            if self.exchange == "device":
+                self.pt.copy_live_count(b, self._mine.data_ptr())
+                self.dist.all_gather_into_tensor(self._all, self._mine)
+                self._base.copy_(self._all[: self.rank].sum().to(torch.int32).reshape(1) if self.rank
+                                 else torch.zeros(1, dtype=torch.int32, device="cuda"))
+            else:
+                counts = [None] * self.world
+                self.dist.all_gather_object(counts, self.pt.read_live_count(b))
+                self._base.copy_(torch.tensor([slot_base_from_counts(counts, self.rank)], dtype=torch.int32))
             self.pt.trace_bounce(b, self._base.data_ptr())
         self.pt.trace_end()
+
+
+class BandGather:
+    """Present-time gather of the ranks' rows on rank 0 through the library (ptc_band_* / ptc_gather_frame: HIP
+    inter-process memory, device-to-device copies into the root; xGMI between GPUs).  `dist` carries the handles
+    (once) and the "rows are published" barrier (every present)."""
+
+    def __init__(self, path_tracer, rank, world, dist):
+        self.pt, self.rank, self.world, self.dist = path_tracer, rank, world, dist
+        if world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, path_tracer.band_export() if rank else b"")
+            if rank == 0:
+                for r in range(1, world):
+                    path_tracer.band_import(r, handles[r])
+
+    def gather(self, which="color", dev_ptr=None):
+        """collective; returns the frame on rank 0 (None elsewhere, or when dev_ptr is given)"""
+        if self.world > 1:
+            if self.rank:
+                self.pt.band_publish(which)
+            self.dist.barrier()
+        out = self.pt.gather_frame(which, dev_ptr) if self.rank == 0 else None
+        if self.world > 1:
+            self.dist.barrier()   # nobody overwrites its exported rows before the root has pulled them
+        return out

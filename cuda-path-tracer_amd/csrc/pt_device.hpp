@@ -218,6 +218,8 @@ void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, u
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);
 void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst);
+void launch_scatter_band(hipStream_t s, const float* src, DBand band, uint32_t pix_count, int channels, float* frame);
+void launch_preview_packed(hipStream_t s, const float* buf, uint32_t pix_count, int channels, int mode, uint32_t* rgba);
 void launch_denoise_positions(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* nd, float4* pos);
 void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* color, const float4* nd,
                          const float4* pos, float4* out, int step_width, DDenoise params);

@@ -1644,6 +1644,36 @@ __global__ __launch_bounds__(256) void k_preview(const float4* buf, uint32_t pix
   rgba[i] = to255(c.x) | (to255(c.y) << 8) | (to255(c.z) << 16) | (alpha << 24);
 }
 
+// A rank's packed rows (3 floats per pixel, or 1) into their place in the whole frame (multi-GPU gather on the root)
+__global__ __launch_bounds__(256) void k_scatter_band(const float* src, DBand band, uint32_t pix_count, int channels, float* frame)
+{
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= pix_count) return;
+  const size_t pixel = band_pixel(band, s);
+  for (int c = 0; c < channels; ++c) frame[pixel * (size_t)channels + (size_t)c] = src[(size_t)s * (size_t)channels + (size_t)c];
+}
+
+// preview_kernel / preview_depth_kernel on a packed frame (the gathered frame of a multi-GPU run)
+__global__ __launch_bounds__(256) void k_preview_packed(const float* buf, uint32_t pix_count, int channels, int mode, uint32_t* rgba)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= pix_count) return;
+  f3 c;
+  uint32_t alpha = 255u;
+  if (mode == 2) {
+    const float d = 1.0f / buf[(size_t)i * (size_t)channels];
+    c = mk3(d, d, d);
+    alpha = 1u;
+  } else {
+    c = mk3(buf[3u * (size_t)i], buf[3u * (size_t)i + 1u], buf[3u * (size_t)i + 2u]);
+    if (mode == 1) c = c * 0.5f + mk3(0.5f, 0.5f, 0.5f);
+  }
+  const float g = 1.f / 2.2f;
+  c = mk3(powf(c.x, g), powf(c.y, g), powf(c.z, g));
+  auto to255 = [](float x) -> uint32_t { return (uint32_t)(unsigned char)(sel_min(sel_max(x, 0.f), 1.f) * 255.99f); };
+  rgba[i] = to255(c.x) | (to255(c.y) << 8) | (to255(c.z) << 16) | (alpha << 24);
+}
+
 // float4 framebuffer -> packed vec3 (which 0) or the w channel (which 1)
 __global__ __launch_bounds__(256) void k_pack(const float4* buf, uint32_t pix_count, int which, float* dst)
 {
@@ -1846,6 +1876,14 @@ void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, u
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba)
 {
   hipLaunchKernelGGL(k_preview, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, buf, pix_count, mode, rgba);
+}
+void launch_scatter_band(hipStream_t s, const float* src, DBand band, uint32_t pix_count, int channels, float* frame)
+{
+  hipLaunchKernelGGL(k_scatter_band, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, src, band, pix_count, channels, frame);
+}
+void launch_preview_packed(hipStream_t s, const float* buf, uint32_t pix_count, int channels, int mode, uint32_t* rgba)
+{
+  hipLaunchKernelGGL(k_preview_packed, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, buf, pix_count, channels, mode, rgba);
 }
 void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst)
 {

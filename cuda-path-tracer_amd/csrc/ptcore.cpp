@@ -121,6 +121,21 @@ struct ptc_ctx {
   float* pack_buf = nullptr;     // 3 floats / pixel staging for downloads
   uint32_t* rgba_buf = nullptr;  // staging for host presents
   DeviceCounters* misc_counters = nullptr;  // flags of kernels outside the frame loop (ptc_intersect_rays)
+  uint32_t slot_offset = 0;                 // "slot_offset" (multi-GPU: distinct random streams per rank)
+  uint32_t* slot_offset_dev = nullptr;
+  hipEvent_t xstream_event = nullptr;       // orders the stepwise calls between a frame's stream and ctx->stream
+  // several GPUs (ptc_band_*): this rank's exported band buffer, and on the root the peers' mapped buffers
+  float* band_buf = nullptr;                // 3 floats per pixel of pix_capacity
+  struct Peer {
+    void* mapped = nullptr;                 // hipIpcOpenMemHandle (foreign process) -- or the pointer itself (same process)
+    bool opened = false;
+    ptc_band_handle h{};
+  };
+  std::vector<Peer> peers;                  // by rank
+  float* gather_stage = nullptr;            // root: a peer's band, copied over before it is scattered into rows
+  float* gather_frame = nullptr;            // root: the whole frame, 3 floats per pixel
+  uint32_t* gather_rgba = nullptr;
+  size_t gather_stage_px = 0;
 
   int iteration = 0;
   int max_iterations = 1;
@@ -378,8 +393,12 @@ int ptc_create(const ptc_config* config, ptc_ctx** out)
   ctx->misc_counters = static_cast<DeviceCounters*>(p);
   if (hipMemset(ctx->misc_counters, 0, sizeof(DeviceCounters)) != hipSuccess) return bail(fail(ctx, PTC_ERR_HIP, "hipMemset failed"));
   if (hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->xstream_event, hipEventDisableTiming) != hipSuccess)
     return bail(fail(ctx, PTC_ERR_HIP, "hipEventCreate failed"));
+  if (hipMalloc(&p, 256) != hipSuccess) return bail(fail(ctx, PTC_ERR_OOM, "hipMalloc(slot offset) failed"));
+  ctx->slot_offset_dev = static_cast<uint32_t*>(p);
+  if (hipMemset(ctx->slot_offset_dev, 0, 256) != hipSuccess) return bail(fail(ctx, PTC_ERR_HIP, "hipMemset failed"));
   *out = ctx;
   return PTC_OK;
 }
@@ -401,6 +420,12 @@ void ptc_destroy(ptc_ctx* ctx)
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
   if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
   if (ctx->main_event) (void)hipEventDestroy(ctx->main_event);
+  if (ctx->xstream_event) (void)hipEventDestroy(ctx->xstream_event);
+  for (auto& peer : ctx->peers)
+    if (peer.opened && peer.mapped) (void)hipIpcCloseMemHandle(peer.mapped);
+  for (void* q : {(void*)ctx->band_buf, (void*)ctx->gather_stage, (void*)ctx->gather_frame, (void*)ctx->gather_rgba,
+                  (void*)ctx->slot_offset_dev})
+    if (q) (void)hipFree(q);
   if (ctx->misc_counters) (void)hipFree(ctx->misc_counters);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -564,6 +589,17 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   ctx->pack_buf = nullptr;
   ctx->rgba_buf = nullptr;
   ctx->have_cam = false;
+  // band / gather buffers belong to the old frame size (an exported handle dies with its buffer: export again)
+  for (auto& peer : ctx->peers)
+    if (peer.opened && peer.mapped) (void)hipIpcCloseMemHandle(peer.mapped);
+  ctx->peers.clear();
+  for (float** q : {&ctx->band_buf, &ctx->gather_stage, &ctx->gather_frame}) {
+    if (*q) (void)hipFree(*q);
+    *q = nullptr;
+  }
+  if (ctx->gather_rgba) (void)hipFree(ctx->gather_rgba);
+  ctx->gather_rgba = nullptr;
+  ctx->gather_stage_px = 0;
   const size_t P = (size_t)width * height;
   auto& pool = ctx->frame_allocs;
   const size_t chunks = (P + kChunk - 1) / kChunk;
@@ -767,6 +803,13 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->scene.refill_lanes = ctx->refill_lanes;
     return PTC_OK;
   }
+  if (std::strcmp(name, "slot_offset") == 0) {
+    if (value < 0) return fail(ctx, PTC_ERR_INVALID, "slot_offset must not be negative");
+    if (int rc = bind_device(ctx)) return rc;
+    ctx->slot_offset = (uint32_t)value;
+    HIP_TRY(ctx, hipMemcpy(ctx->slot_offset_dev, &ctx->slot_offset, sizeof(uint32_t), hipMemcpyHostToDevice));
+    return PTC_OK;
+  }
   if (std::strcmp(name, "frames_in_flight") == 0) {
     if (value < 1 || value > 256) return fail(ctx, PTC_ERR_INVALID, "frames_in_flight must be in [1,256]");
     if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set frames_in_flight before ptc_resize");
@@ -934,7 +977,7 @@ int flush_pending(ptc_ctx* ctx)
   items.swap(ctx->pending);
   if (int rc = batch_begin(ctx, items.data(), (int)items.size())) return rc;
   for (int b = 0; b < ctx->max_bounces; ++b)
-    if (int rc = batch_bounce(ctx, b, nullptr)) {
+    if (int rc = batch_bounce(ctx, b, ctx->slot_offset ? ctx->slot_offset_dev : nullptr)) {
       ctx->active_slot = -1;
       return rc;
     }
@@ -960,6 +1003,14 @@ int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   if (int rc = frame_ready(ctx)) return rc;
   if (ctx->active_slot < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_trace_begin missing");
   if (bounce < 0 || bounce >= ctx->max_bounces) return fail(ctx, PTC_ERR_INVALID, "bounce out of range");
+  if (slot_base_dev) {
+    // the slot base was produced by work on the context's stream (the caller's collective): the frame's stream waits
+    auto& sl = ctx->slots[(size_t)ctx->active_slot];
+    if (sl.stream != ctx->stream) {
+      HIP_TRY(ctx, hipEventRecord(ctx->xstream_event, ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->xstream_event, 0));
+    }
+  }
   return batch_bounce(ctx, bounce, slot_base_dev);
 }
 
@@ -990,6 +1041,10 @@ int ptc_copy_live_count(ptc_ctx* ctx, int bounce, void* dst_dev)
   if (int rc = bind_device(ctx)) return rc;
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
   HIP_TRY(ctx, hipMemcpyAsync(dst_dev, &sl.counters->live[bounce], sizeof(uint32_t), hipMemcpyDeviceToDevice, sl.stream));
+  if (sl.stream != ctx->stream) {  // what the caller enqueues on the context's stream next (an all-gather) sees the value
+    HIP_TRY(ctx, hipEventRecord(ctx->xstream_event, sl.stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->xstream_event, 0));
+  }
   return PTC_OK;
 }
 
@@ -1144,6 +1199,143 @@ int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device)
   if (int rc = check_last(ctx, "pack")) return rc;
   if (!dst_is_device) HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->pack_buf, floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PTC_OK;
+}
+
+// ---- several GPUs: bands over HIP inter-process memory (include/ptcore.h) -------------------------------------------
+static int band_pack(ptc_ctx* ctx, int which, float* dst, size_t* floats)
+{
+  const float4* src = nullptr;
+  int sel = 0;
+  *floats = (size_t)ctx->pix_count * 3u;
+  switch (which) {
+  case PTC_BUF_COLOR: src = ctx->fb.color4; break;
+  case PTC_BUF_NORMAL: src = ctx->fb.nd4; break;
+  case PTC_BUF_DEPTH: src = ctx->fb.nd4; sel = 1; *floats = ctx->pix_count; break;
+  case PTC_BUF_FINAL: src = ctx->result; break;
+  default: return fail(ctx, PTC_ERR_INVALID, "unknown buffer");
+  }
+  if (int rc = sync_frames(ctx)) return rc;
+  launch_pack(ctx->stream, src, ctx->pix_count, sel, dst);
+  return check_last(ctx, "pack");
+}
+
+int ptc_band_export(ptc_ctx* ctx, ptc_band_handle* out)
+{
+  if (!ctx || !out) return PTC_ERR_INVALID;
+  if (!ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "ptc_resize first");
+  if (int rc = bind_device(ctx)) return rc;
+  if (!ctx->band_buf) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->band_buf), (size_t)ctx->pix_capacity * 3u * sizeof(float)));
+  std::memset(out, 0, sizeof *out);
+  hipIpcMemHandle_t h;
+  static_assert(sizeof h <= sizeof out->ipc_mem, "ipc handle size");
+  HIP_TRY(ctx, hipIpcGetMemHandle(&h, ctx->band_buf));
+  std::memcpy(out->ipc_mem, &h, sizeof h);
+  out->pix_count = ctx->pix_count;
+  out->pix_begin = ctx->band.pix_begin;
+  out->width = ctx->width;
+  out->rank = ctx->band.rank;
+  out->nranks = ctx->band.nranks;
+  out->block_rows = ctx->band.block_rows;
+  return PTC_OK;
+}
+
+int ptc_band_import(ptc_ctx* root, uint32_t rank, const ptc_band_handle* handle)
+{
+  if (!root || !handle || rank > 0xffffu) return PTC_ERR_INVALID;
+  if (!root->pix_capacity) return fail(root, PTC_ERR_INVALID, "ptc_resize first");
+  if (handle->width != root->width) return fail(root, PTC_ERR_INVALID, "band of another frame width");
+  if ((uint64_t)handle->pix_count > (uint64_t)root->width * root->height) return fail(root, PTC_ERR_INVALID, "band larger than the frame");
+  if (int rc = bind_device(root)) return rc;
+  if (root->peers.size() <= rank) root->peers.resize((size_t)rank + 1u);
+  auto& peer = root->peers[rank];
+  if (peer.opened && peer.mapped) (void)hipIpcCloseMemHandle(peer.mapped);
+  peer = ptc_ctx::Peer{};
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle->ipc_mem, sizeof h);
+  HIP_TRY(root, hipIpcOpenMemHandle(&peer.mapped, h, hipIpcMemLazyEnablePeerAccess));
+  peer.opened = true;
+  peer.h = *handle;
+  return PTC_OK;
+}
+
+int ptc_band_publish(ptc_ctx* ctx, int which)
+{
+  if (!ctx) return PTC_ERR_INVALID;
+  if (!ctx->band_buf) return fail(ctx, PTC_ERR_INVALID, "ptc_band_export first");
+  if (int rc = bind_device(ctx)) return rc;
+  size_t floats = 0;
+  if (int rc = band_pack(ctx, which, ctx->band_buf, &floats)) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the rows are in the exported buffer when this returns
+  return PTC_OK;
+}
+
+static int gather_rows(ptc_ctx* root, int which, int channels)
+{
+  const size_t P = (size_t)root->width * root->height;
+  if (!root->gather_frame) HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->gather_frame), P * 3u * sizeof(float)));
+  if (!root->band_buf) HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->band_buf), (size_t)root->pix_capacity * 3u * sizeof(float)));
+  // the root's own rows
+  size_t floats = 0;
+  if (int rc = band_pack(root, which, root->band_buf, &floats)) return rc;
+  launch_scatter_band(root->stream, root->band_buf, root->band, root->pix_count, channels, root->gather_frame);
+  // every imported rank's rows: one device-to-device copy out of the peer's buffer (xGMI when it lives on another
+  // GPU), then into row order
+  for (size_t r = 0; r < root->peers.size(); ++r) {
+    const auto& peer = root->peers[r];
+    if (!peer.mapped) continue;
+    if (peer.h.pix_count > root->gather_stage_px) {
+      HIP_TRY(root, hipStreamSynchronize(root->stream));
+      if (root->gather_stage) HIP_TRY(root, hipFree(root->gather_stage));
+      root->gather_stage = nullptr;
+      root->gather_stage_px = 0;
+      HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->gather_stage), (size_t)peer.h.pix_count * 3u * sizeof(float)));
+      root->gather_stage_px = peer.h.pix_count;
+    }
+    HIP_TRY(root, hipMemcpyAsync(root->gather_stage, peer.mapped, (size_t)peer.h.pix_count * (size_t)channels * sizeof(float),
+                                 hipMemcpyDeviceToDevice, root->stream));
+    const DBand band{peer.h.pix_begin, peer.h.width, peer.h.rank, peer.h.nranks, peer.h.block_rows};
+    launch_scatter_band(root->stream, root->gather_stage, band, peer.h.pix_count, channels, root->gather_frame);
+  }
+  return check_last(root, "gather");
+}
+
+int ptc_gather_frame(ptc_ctx* root, int which, void* dst, int dst_is_device)
+{
+  if (!root || !dst) return PTC_ERR_INVALID;
+  if (!root->pix_capacity) return fail(root, PTC_ERR_INVALID, "ptc_resize first");
+  if (which < PTC_BUF_COLOR || which > PTC_BUF_FINAL) return fail(root, PTC_ERR_INVALID, "unknown buffer");
+  if (int rc = bind_device(root)) return rc;
+  const int channels = which == PTC_BUF_DEPTH ? 1 : 3;
+  if (int rc = gather_rows(root, which, channels)) return rc;
+  const size_t bytes = (size_t)root->width * root->height * (size_t)channels * sizeof(float);
+  HIP_TRY(root, hipMemcpyAsync(dst, root->gather_frame, bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, root->stream));
+  HIP_TRY(root, hipStreamSynchronize(root->stream));
+  return PTC_OK;
+}
+
+int ptc_gather_present_rgba8(ptc_ctx* root, void* dst, int dst_is_device, int display_type)
+{
+  if (!root || !dst) return PTC_ERR_INVALID;
+  if (!root->pix_capacity) return fail(root, PTC_ERR_INVALID, "ptc_resize first");
+  if (int rc = bind_device(root)) return rc;
+  int which = PTC_BUF_COLOR, mode = 0;
+  switch (display_type) {
+  case PTC_DISPLAY_FINAL:
+  case PTC_DISPLAY_COLOR: break;
+  case PTC_DISPLAY_NORMAL: which = PTC_BUF_NORMAL; mode = 1; break;
+  case PTC_DISPLAY_DEPTH: which = PTC_BUF_DEPTH; mode = 2; break;
+  default: return fail(root, PTC_ERR_INVALID, "unknown display type");
+  }
+  const int channels = which == PTC_BUF_DEPTH ? 1 : 3;
+  if (int rc = gather_rows(root, which, channels)) return rc;
+  const uint32_t P = root->width * root->height;
+  if (!root->gather_rgba) HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->gather_rgba), (size_t)P * 4u));
+  uint32_t* out = dst_is_device ? static_cast<uint32_t*>(dst) : root->gather_rgba;
+  launch_preview_packed(root->stream, root->gather_frame, P, channels, mode, out);
+  if (int rc = check_last(root, "preview")) return rc;
+  if (!dst_is_device) HIP_TRY(root, hipMemcpyAsync(dst, root->gather_rgba, (size_t)P * 4u, hipMemcpyDeviceToHost, root->stream));
+  HIP_TRY(root, hipStreamSynchronize(root->stream));
   return PTC_OK;
 }
 

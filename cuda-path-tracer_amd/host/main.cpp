@@ -3,8 +3,19 @@
 // following the call sequence of execute_cli_version (src/cli/cli.cpp:62-116): read scene, create_buffers,
 // max_iterations = spp, spp x path_trace, synchronize, send_to_preview, write PNG, stage timings.
 // Extra flags: --max-bounces N (the reference's cap is a compile-time 50), --denoise, --method, --gpu,
-// --dump-scene FILE (flattened scene arrays, for tests; needs no GPU).  Without -o the reference opens its
+// --dump-scene FILE (flattened scene arrays, for tests; needs no GPU), --gpus N.  Without -o the reference opens its
 // GLFW viewer; this build is headless and says so.
+//
+// --gpus N: one PROCESS per GPU (forked before anything touches HIP), rank r on device r % device_count.  The frame's
+// rows are dealt to the ranks in blocks of 8 (ptc_set_interleave: sky rows are cheap, terrain rows expensive), the
+// scene is replicated, nobody talks while tracing, and at the end every rank's rows go straight to rank 0 through the
+// library's inter-process gather (ptc_band_export / import / publish, ptc_gather_present_rgba8: device-to-device
+// copies, xGMI between GPUs).  Handles and the two barriers travel through a shared-memory page.
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -29,6 +40,7 @@ struct CliConfigurations {  // configurations.hpp:11-15
   bool denoise = false;
   bool megakernel = false;
   int gpu = 0;
+  int gpus = 1;
   std::optional<std::string> dump_scene;
 };
 
@@ -43,6 +55,7 @@ void usage()
                "      --denoise        run the A-Trous denoiser before writing the image\n"
                "      --method M       streaming (default) | megakernel\n"
                "      --gpu N          HIP device ordinal\n"
+               "      --gpus N         split the frame's rows over N processes / GPUs (rank r on device r %% device count)\n"
                "      --dump-scene F   write the flattened scene to F and exit (no GPU needed)\n");
 }
 
@@ -69,6 +82,7 @@ CliConfigurations parse_cli_args(int argc, char** argv)
     else if (a == "--denoise") c.denoise = true;
     else if (a == "--method") c.megakernel = need("method") == "megakernel";
     else if (a == "--gpu") c.gpu = std::stoi(need("gpu"));
+    else if (a == "--gpus") c.gpus = std::stoi(need("gpus"));
     else if (a == "--dump-scene") c.dump_scene = need("dump-scene");
     else if (!a.empty() && a[0] == '-') {
       std::fprintf(stderr, "Option '%s' does not exist\n", a.c_str());
@@ -121,6 +135,136 @@ void dump_vec(std::ofstream& out, const std::vector<T>& v)
   out.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(n * sizeof(T)));
 }
 
+// ---- --gpus N -------------------------------------------------------------------------------------------------
+constexpr int kMaxRanks = 64;
+constexpr uint32_t kBlockRows = 8;
+struct Shared {  // one MAP_SHARED page set up before the fork
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  std::atomic<int> failed;
+  ptc_band_handle handles[kMaxRanks];
+  unsigned long long rays[kMaxRanks];
+};
+
+// all ranks meet; false when a rank has failed or nothing happens for two minutes
+bool barrier(Shared* sh, int n)
+{
+  const uint32_t gen = sh->generation.load();
+  if (sh->arrived.fetch_add(1u) + 1u == (uint32_t)n) {
+    sh->arrived.store(0u);
+    sh->generation.fetch_add(1u);
+    return sh->failed.load() == 0;
+  }
+  for (int waited_ms = 0; sh->generation.load() == gen; ++waited_ms) {
+    if (sh->failed.load() != 0 || waited_ms > 120000) return false;
+    usleep(1000);
+  }
+  return sh->failed.load() == 0;
+}
+
+int run_rank(const CliConfigurations& configs, const SceneDescription& scene_desc, Shared* sh, int rank, int world)
+try {
+  int devices = 0;
+  if (ptc_device_count(&devices) < 0 || devices <= 0) throw std::runtime_error("no HIP device");
+  const UResolution resolution{(unsigned)scene_desc.resolution[0], (unsigned)scene_desc.resolution[1]};
+  const int spp = scene_desc.spp;
+  Stopwatch stopwatch;
+  PathTracer path_tracer{rank % devices};
+  path_tracer.max_bounces = configs.max_bounces;
+  path_tracer.create_buffers(resolution, scene_desc);
+  auto check = [&](int rc, const char* what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + ptc_last_error(path_tracer.handle()));
+  };
+  check(ptc_set_interleave(path_tracer.handle(), (uint32_t)rank, (uint32_t)world, kBlockRows), "set_interleave");
+  // every rank numbers its paths from 0: an offset keeps the ranks' random streams apart (path_tracer.cu:300)
+  check(ptc_set_param(path_tracer.handle(), "slot_offset", (int)((unsigned)rank * resolution.width * resolution.height)), "slot_offset");
+  if (rank != 0) check(ptc_band_export(path_tracer.handle(), &sh->handles[rank]), "band_export");
+  path_tracer.synchronize();
+  if (!barrier(sh, world)) throw std::runtime_error("another rank failed during set-up");
+  if (rank == 0) {
+    for (int r = 1; r < world; ++r) check(ptc_band_import(path_tracer.handle(), (uint32_t)r, &sh->handles[r]), "band_import");
+    std::printf("Start path tracing\nspp: %d\nwidth: %u, height: %u\nranks: %d on %d device(s)\n", spp, resolution.width,
+                resolution.height, world, devices);
+  }
+  stopwatch.end_stage("Initialization");
+  path_tracer.max_iterations = spp;
+  for (int i = 0; i < spp; ++i) path_tracer.path_trace(scene_desc.camera, resolution);
+  if (rank != 0) check(ptc_band_publish(path_tracer.handle(), PTC_BUF_COLOR), "band_publish");
+  else path_tracer.synchronize();
+  sh->rays[rank] = path_tracer.stats().rays_total;
+  if (!barrier(sh, world)) throw std::runtime_error("another rank failed while tracing");
+  stopwatch.end_stage("Path Tracing");
+  if (rank == 0) {
+    std::vector<uchar4> buffer((size_t)resolution.width * resolution.height);
+    check(ptc_gather_present_rgba8(path_tracer.handle(), buffer.data(), 0, PTC_DISPLAY_FINAL), "gather_present");
+    const fs::path output_path{*configs.output_filename};
+    if (output_path.extension() == ".png") {
+      if (!write_png(output_path.string(), (int)resolution.width, (int)resolution.height, buffer.data()))
+        std::fprintf(stderr, "Failed to write to image file %s\n", output_path.string().c_str());
+    } else {
+      std::fprintf(stderr, "%s has an unrecognized extension\n", output_path.string().c_str());
+    }
+    stopwatch.end_stage("Gather + write image file");
+  }
+  if (!barrier(sh, world)) throw std::runtime_error("another rank failed at the end");  // peers keep their rows until here
+  if (rank == 0) {
+    unsigned long long rays = 0;
+    for (int r = 0; r < world; ++r) rays += sh->rays[r];
+    std::printf("Done path tracing %s!\n\n", scene_desc.filename.c_str());
+    stopwatch.report();
+    std::printf("rays: %llu over %d ranks\n", rays, world);
+  }
+  return 0;
+} catch (const std::exception& e) {
+  sh->failed.store(1);
+  std::fprintf(stderr, "hip_pt rank %d fatal error: %s\n", rank, e.what());
+  return 1;
+}
+
+int run_ranks(const CliConfigurations& configs, const SceneDescription& scene_desc)
+{
+  const int world = configs.gpus;
+  if (world > kMaxRanks) {
+    std::fprintf(stderr, "hip_pt: at most %d ranks\n", kMaxRanks);
+    return 1;
+  }
+  if (configs.denoise || configs.megakernel) {
+    std::fprintf(stderr, "hip_pt: --gpus N renders in streaming mode without the denoiser (it needs the whole frame in one context)\n");
+    return 1;
+  }
+  void* page = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (page == MAP_FAILED) {
+    std::perror("mmap");
+    return 1;
+  }
+  Shared* sh = new (page) Shared{};
+  std::fflush(stdout);
+  std::fflush(stderr);
+  std::vector<pid_t> children;
+  for (int r = 0; r < world; ++r) {
+    const pid_t pid = fork();  // nothing in this process has touched HIP yet
+    if (pid < 0) {
+      std::perror("fork");
+      sh->failed.store(1);
+      break;
+    }
+    if (pid == 0) {
+      const int rc = run_rank(configs, scene_desc, sh, r, world);
+      std::fflush(stdout);
+      std::fflush(stderr);
+      _exit(rc);
+    }
+    children.push_back(pid);
+  }
+  int rc = sh->failed.load() ? 1 : 0;
+  for (pid_t pid : children) {
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) rc = 1;
+  }
+  munmap(page, sizeof(Shared));
+  return rc;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -167,6 +311,8 @@ try {
     std::fprintf(stderr, "hip_pt: this build is headless (no GLFW viewer); give -o <file.png>\n");
     return 1;
   }
+
+  if (configs.gpus > 1) return run_ranks(configs, scene_desc);
 
   const UResolution resolution{(unsigned)scene_desc.resolution[0], (unsigned)scene_desc.resolution[1]};
   const int spp = scene_desc.spp;

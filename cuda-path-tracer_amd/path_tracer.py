@@ -165,6 +165,40 @@ class PathTracer:
         self._check(self._lib.ptc_read_live_count(self._ctx, int(bounce), C.byref(v)))
         return int(v.value)
 
+    # -- several GPUs: bands over HIP inter-process memory (include/ptcore.h) -----------------------------------
+    def band_export(self):
+        """bytes of this rank's ptc_band_handle (to be sent to the root over the application's own channel)"""
+        h = _capi.ptc_band_handle()
+        self._check(self._lib.ptc_band_export(self._ctx, C.byref(h)))
+        return bytes(h)
+
+    def band_import(self, rank, handle_bytes):
+        h = _capi.ptc_band_handle.from_buffer_copy(handle_bytes)
+        self._check(self._lib.ptc_band_import(self._ctx, int(rank), C.byref(h)))
+
+    def band_publish(self, which="color"):
+        sel = {"color": _capi.BUF_COLOR, "normal": _capi.BUF_NORMAL, "depth": _capi.BUF_DEPTH, "final": _capi.BUF_FINAL}[which]
+        self._check(self._lib.ptc_band_publish(self._ctx, sel))
+
+    def gather_frame(self, which="color", dev_ptr=None):
+        """root: the whole frame [h, w, 3] (or [h, w] for depth) from its own rows and the published rows of the
+        imported ranks; into a device pointer when given"""
+        sel = {"color": _capi.BUF_COLOR, "normal": _capi.BUF_NORMAL, "depth": _capi.BUF_DEPTH, "final": _capi.BUF_FINAL}[which]
+        w, h = self._resolution
+        if dev_ptr is not None:
+            self._check(self._lib.ptc_gather_frame(self._ctx, sel, C.c_void_p(int(dev_ptr)), 1))
+            return None
+        ch = 1 if which == "depth" else 3
+        out = np.empty(w * h * ch, dtype=np.float32)
+        self._check(self._lib.ptc_gather_frame(self._ctx, sel, out.ctypes.data_as(C.c_void_p), 0))
+        return out.reshape(h, w) if ch == 1 else out.reshape(h, w, 3)
+
+    def gather_present(self, display_type=DisplayBufferType.final):
+        w, h = self._resolution
+        out = np.empty((h * w, 4), dtype=np.uint8)
+        self._check(self._lib.ptc_gather_present_rgba8(self._ctx, out.ctypes.data_as(C.c_void_p), 0, int(display_type)))
+        return out.reshape(h, w, 4)
+
     def synchronize(self):
         self._check(self._lib.ptc_synchronize(self._ctx))
 

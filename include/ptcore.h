@@ -218,6 +218,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   A batch of a single iteration (an interactive front-end that presents or denoises after every iteration, the
  *   stepwise calls) runs in one of eight extra one-frame slots with streams of their own, so that viewer-style
  *   use keeps eight frames in flight as well (config 5, 1 spp + denoise per 1080p frame: 1.6 ms)
+ *   "slot_offset"      added to every compacted slot index before the material RNG is seeded (path_tracer.cu:300).  A
+ *                      rank of a multi-GPU run that numbers its paths locally (ptc_set_interleave) sets rank * (pixels of
+ *                      the largest share) so that no two ranks draw the same random streams; 0 (default) = the reference
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 3 = 3/8)
  *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small
@@ -243,8 +246,11 @@ int ptc_trace_begin(ptc_ctx* ctx, const ptc_camera* camera);
 int ptc_trace_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev);
 int ptc_trace_end(ptc_ctx* ctx);
 int ptc_live_count_dev(ptc_ctx* ctx, int bounce, const uint32_t** dev_ptr);
-/* Enqueue (on the frame's stream) a copy of that counter into a caller-owned device uint32, e.g. a torch tensor
- * that is then all-gathered over RCCL.  Only inside ptc_trace_begin .. ptc_trace_end. */
+/* Enqueue a copy of that counter into a caller-owned device uint32, e.g. a torch tensor that is then all-gathered
+ * over RCCL.  Only inside ptc_trace_begin .. ptc_trace_end.  Ordering: the copy runs on the frame's own stream and
+ * the context's stream (ptc_set_stream, e.g. torch's current stream) is made to wait for it, so work the caller
+ * enqueues there afterwards sees the value; ptc_trace_bounce in turn makes the frame's stream wait for everything
+ * enqueued on the context's stream so far before it reads slot_base_dev.  No host synchronisation. */
 int ptc_copy_live_count(ptc_ctx* ctx, int bounce, void* dst_dev);
 /* The same value on the host (synchronises the frame's stream): the per-bounce read-back the reference does
  * after every thrust::stable_partition (path_tracer.cu:457). */
@@ -262,6 +268,38 @@ int ptc_present_rgba8(ptc_ctx* ctx, void* dst, int dst_is_device, int display_ty
  * for COLOR/NORMAL/FINAL (glm::vec3 layout of dev_color_buffer_ etc., path_tracer.hpp:73-81),
  * 1 per pixel for DEPTH.  Synchronises. */
 int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device);
+
+/* ---- several GPUs: one process and one context per GPU, the frame's rows dealt to the ranks ---- */
+/* (No reference equivalent: the reference is single-GPU.  SURVEY section 8e: the scene is replicated, every rank
+ * traces its rows (ptc_set_interleave / ptc_set_rows) without talking to anyone, and radiance moves only at present
+ * time, from every rank straight to the root over xGMI.)
+ * The transport is HIP inter-process memory: a rank exports the device buffer that holds its packed rows
+ * (ptc_band_export, once), the root maps the peers' buffers (ptc_band_import, once) and pulls them with
+ * device-to-device copies whenever a frame is presented (ptc_gather_frame / ptc_gather_present_rgba8).  The handles
+ * and the "my rows are ready" signal travel over whatever channel the application has between its processes --
+ * shared memory in hip_pt --gpus N (host/main.cpp), torch.distributed in bench.py and the tests:
+ *     every rank but the root:  ptc_band_publish(ctx, which);   then signal / barrier
+ *     the root, after that:     ptc_gather_frame(ctx, which, dst, dst_is_device)
+ * Works the same when the ranks share one GPU (how it is tested on a one-GPU box). */
+typedef struct ptc_band_handle {
+  uint8_t ipc_mem[64];     /* hipIpcMemHandle_t of the rank's band buffer (3 floats per pixel of the band) */
+  uint32_t pix_count;      /* pixels the rank renders */
+  uint32_t pix_begin;      /* DBand of the rank: where its packed pixel s sits in the frame */
+  uint32_t width;
+  uint32_t rank, nranks, block_rows;
+  uint32_t reserved[2];
+} ptc_band_handle;
+int ptc_band_export(ptc_ctx* ctx, ptc_band_handle* out);
+int ptc_band_import(ptc_ctx* root, uint32_t rank, const ptc_band_handle* handle);
+/* Pack this rank's rows of buffer `which` (ptc_buffer) into its exported band buffer and wait until they are there. */
+int ptc_band_publish(ptc_ctx* ctx, int which);
+/* Root: its own rows + the rows every imported rank has published -> the whole frame in row order, packed like
+ * ptc_download (3 floats per pixel, 1 for PTC_BUF_DEPTH).  dst holds width*height pixels.  Synchronises. */
+int ptc_gather_frame(ptc_ctx* root, int which, void* dst, int dst_is_device);
+/* Root: PathTracer::send_to_preview of the gathered frame (width*height RGBA8).  display_type as ptc_present_rgba8;
+ * PTC_DISPLAY_FINAL gathers the accumulated colour (a denoised buffer exists only for a context that owns the whole
+ * frame). */
+int ptc_gather_present_rgba8(ptc_ctx* root, void* dst, int dst_is_device, int display_type);
 
 int ptc_synchronize(ptc_ctx* ctx);                                  /* cudaDeviceSynchronize at cli.cpp:100 */
 int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out);                    /* synchronises */

@@ -1,0 +1,53 @@
+"""The N > 1 path with real processes on the one GPU of the test box: two ranks share cuda:0 and talk over gloo
+(RCCL refuses two ranks on one device), exchange live counts per bounce (global slot numbering: the assembled frame
+must be the single-context frame bit for bit) and move their rows to rank 0 through the library's inter-process
+gather (ptc_band_export / import / publish, ptc_gather_frame, ptc_gather_present_rgba8)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_processes_share_one_gpu(world):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29620 + world), os.path.join(ROOT, "tests", "mp_band_worker.py")]
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert proc.returncode == 0 and "BAND_OK" in proc.stdout, proc.stdout[-4000:]
+
+
+def test_cli_with_ranks(pkg, tmp_path):
+    """hip_pt --gpus 3 (three forked ranks on the one device, rows in blocks of 8, the library's gather at the end)
+    against the Python path doing the same split in one process: the same image, byte for byte."""
+    import numpy as np
+    from PIL import Image
+    hip_pt = os.path.join(ROOT, "cuda-path-tracer_amd", "host", "hip_pt")
+    if not os.path.exists(hip_pt):
+        subprocess.run(["make"], cwd=os.path.dirname(hip_pt), check=True, stdout=subprocess.DEVNULL)
+    scene_file, world, spp, mb = "cornell_mesh.json", 3, 3, 6
+    out = tmp_path / "out.png"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([hip_pt, "scenes/" + scene_file, "-o", str(out), "--spp", str(spp), "--max-bounces", str(mb), "--gpus", str(world)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"ranks: {world}" in r.stdout and "Gather + write image file" in r.stdout
+    got = np.array(Image.open(out))
+    scene = pkg.json_parser.scene_from_json(os.path.join(ROOT, "assets", "scenes", scene_file))
+    w, h = scene.resolution
+    bands = []
+    for rank in range(world):
+        with pkg.PathTracer(max_bounces=mb) as pt:
+            pt.create_buffers(scene.resolution, scene)
+            pt.set_interleave(rank, world, 8)
+            pt.set_param("slot_offset", rank * w * h)
+            pt.max_iterations = spp
+            for _ in range(spp):
+                pt.path_trace(scene.camera)
+            bands.append(pt.send_to_preview())
+    want = pkg.bands.assemble_interleaved(bands, h, world, 8)
+    assert got.shape == want.shape and np.array_equal(got, want)
