@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
+    ap.add_argument("--gather", choices=("rccl", "ipc"), default="rccl",
+                    help="N > 1, present time: rccl = torch.distributed gather of the ranks' rows over RCCL (default); ipc = the "
+                         "library's inter-process gather (ptc_band_* / ptc_gather_frame, what hip_pt --gpus N uses)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--no-events", action="store_true", help="do not time the trace kernel with HIP events (diagnostic)")
@@ -188,6 +191,9 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
         if world > 1:
             pt.set_interleave(rank, world, BLOCK_ROWS)
+            # every rank numbers its compacted paths from 0 (no collective while tracing): an offset keeps the
+            # ranks' random streams apart (the material RNG is keyed on the slot index, path_tracer.cu:300)
+            pt.set_param("slot_offset", rank * W * H)
         pt.max_iterations = 1 << 30
         return pt
 
@@ -201,8 +207,15 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
         row_index = [torch.tensor(rank_rows[r], dtype=torch.long, device="cuda") for r in range(world)]
 
+    ipc_gathers = {}
+
     def present(tracer):
         """gather of per-rank radiance at present time (the only inter-GPU traffic) + back into frame order"""
+        if world > 1 and args.gather == "ipc":
+            if id(tracer) not in ipc_gathers:
+                ipc_gathers[id(tracer)] = pkg.bands.BandGather(tracer, rank, world, dist)
+            ipc_gathers[id(tracer)].gather("color", frame.data_ptr() if rank == 0 else None)
+            return
         tracer.download_to_device("color", band_color.data_ptr())
         if world > 1:
             if rehearse:
@@ -356,7 +369,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                                      "frames; the tuned 32-frame schedule is reported under steady_state"),
                    "rays_per_step": round(rays / args.steps),
                    "live_per_bounce_last_frame_rank0": last_live, "exact_redo_rays": slow_rays,
-                   "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks",
+                   "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks; "
+                                f"present-time gather: {args.gather}",
                    "bvh_build_s": round(bvh_build_s, 3)},
         "roofline": roofline,
         "parity": parity,

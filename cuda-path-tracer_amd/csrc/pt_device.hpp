@@ -182,6 +182,7 @@ struct DCameras {
 
 struct DDenoise {
   float c_phi, n_phi, p_phi;
+  int variant;  // 0: taps staged in LDS per sub-lattice (k_denoise_lds, default); 1: taps through L1 / L2 (k_denoise)
 };
 
 // ---- launch interface (implemented in pt_kernels.hip) ----

@@ -1781,6 +1781,131 @@ __global__ __launch_bounds__(256) void k_denoise(DCamera cam, uint32_t pix_count
   else denoise_pixel<false>(cam, pix_count, color, nd, pos, out, step_width, prm, x, y);
 }
 
+// The same pass with its taps staged in LDS (the default).  The taps of a pixel sit `step` apart: vertically a
+// workgroup works on ONE residue class of rows (y mod step): four lattice rows of outputs need eight lattice rows of
+// taps, whatever the step; horizontally it is dense (64 consecutive pixels of outputs, 2 * step more on either side),
+// so every global load is a coalesced run of pixels and every byte of a fetched cache line is used.  36 bytes per
+// staged pixel (colour, normal, position): (64 + 4 step) x 8 of them, 28 KB at step 8.  Every tap then is three LDS
+// reads instead of three 16-byte global loads through L1: the pass was bound by the L1 / texture-address rate of its 75
+// loads per pixel (110 us at 1080p).  (First attempt, measured: sub-lattices in BOTH directions -- 16x16 outputs from
+// 20x20 staged points at any step -- fetch one cache line per point and array at step 8, and the step x step
+// workgroups that share those lines are dealt round-robin to the eight XCDs, each with its own L2: 171 us for that
+// pass.)  The reference's clamp of a tap coordinate to [0, W] x [0, H] (inclusive: column W aliases the next row, row
+// H is out of bounds; see k_denoise_positions) depends only on the tap's coordinate, not on which output uses it, so it
+// is applied once, when the pixel is staged.
+// kStep is a template parameter (the steps of a denoise call are 1, 2, 4, ...): tap offsets become immediates of the
+// LDS reads -- with a run-time step every tap cost three address additions.
+constexpr int kDenW = 64, kDenRows = 4, kDenHalo = 2;
+template <int kStep>
+__global__ __launch_bounds__(256) void k_denoise_lds(DCamera cam, uint32_t pix_count, const float4* color, const float4* nd,
+                                                     const float4* pos, float4* out, DDenoise prm)
+{
+#pragma clang fp contract(fast)
+  extern __shared__ float4 s_dyn[];
+  constexpr int step = kStep;
+  const int W = (int)cam.width, H = (int)cam.height;
+  constexpr int row_len = kDenW + 2 * kDenHalo * step, rows = kDenRows + 2 * kDenHalo, points = row_len * rows;
+  float4* s_a = s_dyn;                                       // colour.rgb, normal.x
+  float4* s_b = s_dyn + points;                              // normal.yz, position.xy
+  float* s_c = reinterpret_cast<float*>(s_dyn + 2 * points);  // position.z
+  const uint32_t tiles_x = ((uint32_t)W + kDenW - 1u) / kDenW;
+  const uint32_t lattice_rows = ((uint32_t)H + (uint32_t)step - 1u) / (uint32_t)step;
+  const uint32_t tiles_y = (lattice_rows + kDenRows - 1u) / kDenRows;
+  // Workgroups that share staged rows (vertical neighbours of one residue class) must share an L2: workgroup b runs
+  // on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), so every XCD gets one contiguous eighth of the tiles in
+  // (residue, tile row, tile column) order -- a workgroup's vertical neighbour is 30 workgroups away on the same XCD,
+  // about 1 MB of input apart, well inside its 4 MB L2.  Dealt round-robin instead, neighbours land on different
+  // XCDs, every halo row is fetched from the Infinity Cache again, and the pass is bound there (2-3x the bytes).
+  const uint32_t total = tiles_x * tiles_y * (uint32_t)step, per_xcd = (total + 7u) / 8u;
+  uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || b >= total) return;
+  const int tx = (int)(b % tiles_x);
+  b /= tiles_x;
+  const int ty = (int)(b % tiles_y), ry = (int)(b / tiles_y);
+  const int x0 = tx * kDenW - kDenHalo * step;  // first staged column
+  // stage (coordinates may lie outside the image: the reference's clamp).  Three rounds of 256 pixels at a time with
+  // all their global loads issued before the first is used: staged one round after the other, the dependent round
+  // trips (about 2 us each) were most of a workgroup's life and the pass ran at 65-70 us whatever the step
+  constexpr int kRounds = 3;
+  for (int base = 0; base < points; base += 256 * kRounds) {
+    float4 c[kRounds], g[kRounds], q[kRounds];
+    int uu[kRounds], vv[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int k = min(base + r * 256 + (int)threadIdx.x, points - 1);
+      const int li = k % row_len, lj = k / row_len;
+      int u = x0 + li;
+      int v = (ty * kDenRows + lj - kDenHalo) * step + ry;
+      u = u < 0 ? 0 : (u > W ? W : u);
+      v = v < 0 ? 0 : (v > H ? H : v);
+      uint32_t ti = (uint32_t)u + (uint32_t)v * (uint32_t)W;
+      if (ti >= pix_count) ti = pix_count - 1u;
+      uu[r] = u;
+      vv[r] = v;
+      c[r] = color[ti];
+      g[r] = nd[ti];
+      q[r] = pos[ti];
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int k = base + r * 256 + (int)threadIdx.x;
+      f3 p = xyz(q[r]);
+      if (uu[r] == W || vv[r] == H) {  // the reference's off-by-one taps keep their own view ray
+        f3 to, td;
+        generate_ray(cam, (float)uu[r] + 0.5f, (float)vv[r] + 0.5f, to, td);
+        p = to + td * g[r].w;
+      }
+      if (k < points) {
+        s_a[k] = make_float4(c[r].x, c[r].y, c[r].z, g[r].x);
+        s_b[k] = make_float4(g[r].y, g[r].z, p.x, p.y);
+        s_c[k] = p.z;
+      }
+    }
+  }
+  __syncthreads();
+  const int i = (int)(threadIdx.x & 63u), j = (int)(threadIdx.x >> 6);
+  const int x = tx * kDenW + i, y = (ty * kDenRows + j) * step + ry;
+  if (x >= W || y >= H) return;
+  const int centre = (j + kDenHalo) * row_len + i + kDenHalo * step;
+  const float4 ca = s_a[centre], cb = s_b[centre];
+  const f3 cval = mk3(ca.x, ca.y, ca.z), nval = mk3(ca.w, cb.x, cb.y), pval = mk3(cb.z, cb.w, s_c[centre]);
+  const float kernel[3] = {3.f / 8.f, 1.f / 4.f, 1.f / 16.f};
+  const float step2 = (float)(step * step);
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float kc = -kLog2e / prm.c_phi, kn = -kLog2e / (step2 * prm.n_phi), kp = -kLog2e / prm.p_phi;
+  f3 sum = mk3(0.f, 0.f, 0.f);
+  float cum_w = 0.0f;
+  // one tap row per iteration (not unrolled: the fully unrolled 5x5 keeps 130 registers alive -- three wavefronts per
+  // SIMD); the tap weight kernel[min(|dx|, |dy|)] of a row depends on |dx| only through three row constants
+#pragma unroll 1
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int ady = dy < 0 ? -dy : dy;
+    const float w_by_adx[3] = {kernel[0], kernel[ady < 1 ? ady : 1], kernel[ady]};
+    const int row = centre + dy * row_len;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int t = row + dx * step;
+      const float4 ta = s_a[t], tb = s_b[t];
+      const float tz = s_c[t];
+      // (the squared distances written out here, inside the contraction pragma's scope: dot() from pt_math.hpp is
+      // compiled under the file's -ffp-contract=off and kept the pass at 37 instead of 27 instructions per tap)
+      const float cx = cval.x - ta.x, cy = cval.y - ta.y, cz = cval.z - ta.z;
+      const float nx = nval.x - ta.w, ny = nval.y - tb.x, nz = nval.z - tb.y;
+      const float px = pval.x - tb.z, py = pval.y - tb.w, pz = pval.z - tz;
+      const float dc = cx * cx + cy * cy + cz * cz, dn = nx * nx + ny * ny + nz * nz, dp = px * px + py * py + pz * pz;
+      const float arg = dc * kc + dn * kn + dp * kp;
+      const float weight = __builtin_amdgcn_exp2f(arg);
+      const float wk = weight * w_by_adx[dx < 0 ? -dx : dx];
+      sum.x += ta.x * wk;
+      sum.y += ta.y * wk;
+      sum.z += ta.z * wk;
+      cum_w += wk;
+    }
+  }
+  const float inv_w = 1.0f / cum_w;
+  out[(uint32_t)x + (uint32_t)y * (uint32_t)W] = make_float4(sum.x * inv_w, sum.y * inv_w, sum.z * inv_w, 0.0f);
+}
+
 __global__ void k_selftest(const float* a, const float* b, uint32_t n, float* out_div, float* out_sqrt, float* out_sin,
                            float* out_cos)
 {
@@ -1896,8 +2021,25 @@ void launch_denoise_positions(hipStream_t s, const DCamera& cam, uint32_t pix_co
 void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* color, const float4* nd,
                          const float4* pos, float4* out, int step_width, DDenoise params)
 {
-  const uint32_t tiles = div_up(cam.width, 16u) * div_up(cam.height, 16u);
-  hipLaunchKernelGGL(k_denoise, dim3(tiles), dim3(256), 0, s, cam, pix_count, color, nd, pos, out, step_width, params);
+  // (beyond step 32 the staged tile outgrows 64 KB of LDS: such filter sizes take the L1 / L2 kernel, and so does a
+  // step that is no power of two -- ptc_denoise only issues 1, 2, 4, ...)
+  if (params.variant == 1 || step_width > 32 || (step_width & (step_width - 1)) != 0) {  // taps through L1 / L2 (cross-check of the default)
+    const uint32_t tiles = div_up(cam.width, 16u) * div_up(cam.height, 16u);
+    hipLaunchKernelGGL(k_denoise, dim3(tiles), dim3(256), 0, s, cam, pix_count, color, nd, pos, out, step_width, params);
+    return;
+  }
+  const uint32_t st = (uint32_t)step_width;
+  const uint32_t total = div_up(cam.width, (uint32_t)kDenW) * div_up(div_up(cam.height, st), (uint32_t)kDenRows) * st;
+  const dim3 grid(div_up(total, 8u) * 8u), block(256);  // one contiguous eighth of the tiles per XCD (see the kernel)
+  const size_t lds = (size_t)(kDenW + 2 * kDenHalo * step_width) * (size_t)(kDenRows + 2 * kDenHalo) * 36u;
+  switch (step_width) {
+  case 1: hipLaunchKernelGGL(k_denoise_lds<1>, grid, block, lds, s, cam, pix_count, color, nd, pos, out, params); break;
+  case 2: hipLaunchKernelGGL(k_denoise_lds<2>, grid, block, lds, s, cam, pix_count, color, nd, pos, out, params); break;
+  case 4: hipLaunchKernelGGL(k_denoise_lds<4>, grid, block, lds, s, cam, pix_count, color, nd, pos, out, params); break;
+  case 8: hipLaunchKernelGGL(k_denoise_lds<8>, grid, block, lds, s, cam, pix_count, color, nd, pos, out, params); break;
+  case 16: hipLaunchKernelGGL(k_denoise_lds<16>, grid, block, lds, s, cam, pix_count, color, nd, pos, out, params); break;
+  default: hipLaunchKernelGGL(k_denoise_lds<32>, grid, block, lds, s, cam, pix_count, color, nd, pos, out, params); break;
+  }
 }
 void launch_intersect(hipStream_t s, const DScene& scene, const float4* rays_o, const float4* rays_d, uint32_t n,
                       DHits hits, DeviceCounters* counters, int variant)

@@ -158,6 +158,7 @@ struct ptc_ctx {
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
+  int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2
   uint32_t lds_entries = 24;  // == kLds4 in pt_kernels.hip (PT_T4_LDS); fewer only through "debug_lds_entries"
   int force_slow = 0;
 
@@ -803,6 +804,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->scene.refill_lanes = ctx->refill_lanes;
     return PTC_OK;
   }
+  if (std::strcmp(name, "denoise_variant") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "denoise_variant must be 0 or 1");
+    ctx->denoise_variant = value;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "slot_offset") == 0) {
     if (value < 0) return fail(ctx, PTC_ERR_INVALID, "slot_offset must not be negative");
     if (int rc = bind_device(ctx)) return rc;
@@ -1114,7 +1120,7 @@ int ptc_denoise(ptc_ctx* ctx)
   if (ctx->order_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_event, 0));
   else if (!ctx->slots.empty() && ctx->slots[(size_t)ctx->last_slot].stream != ctx->stream)
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slots[(size_t)ctx->last_slot].done, 0));
-  const DDenoise prm{ctx->den.color_weight, ctx->den.normal_weight, ctx->den.position_weight};
+  const DDenoise prm{ctx->den.color_weight, ctx->den.normal_weight, ctx->den.position_weight, ctx->denoise_variant};
   // edge_avoiding_a_trous_denoiser.cu:102-108: (color, back, front) <- (back, front, back) after each pass
   const float4* color = ctx->fb.color4;
   float4* back = ctx->den_a;

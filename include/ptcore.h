@@ -218,6 +218,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   A batch of a single iteration (an interactive front-end that presents or denoises after every iteration, the
  *   stepwise calls) runs in one of eight extra one-frame slots with streams of their own, so that viewer-style
  *   use keeps eight frames in flight as well (config 5, 1 spp + denoise per 1080p frame: 1.6 ms)
+ *   "denoise_variant"  0 (default): the A-Trous passes stage their taps in LDS, one sub-lattice of the dilated filter per
+ *                      workgroup; 1: taps through L1 / L2 (round-1 kernel, kept as a cross-check).  Same results up to
+ *                      summation order (both within 1e-5 of the oracle)
  *   "slot_offset"      added to every compacted slot index before the material RNG is seeded (path_tracer.cu:300).  A
  *                      rank of a multi-GPU run that numbers its paths locally (ptc_set_interleave) sets rank * (pixels of
  *                      the largest share) so that no two ranks draw the same random streams; 0 (default) = the reference

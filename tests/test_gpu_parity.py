@@ -202,6 +202,36 @@ def test_denoise_and_preview_against_oracle(pkg, orc):
     assert np.max(np.abs(dep.astype(int) - want_d.astype(int))) <= 1 and np.all(dep[..., 3] == 1)
 
 
+@pytest.mark.parametrize("size", [(1920, 1080), (101, 67)])
+def test_denoise_kernels_against_oracle(pkg, orc, size):
+    """Both A-Trous kernels (taps staged in LDS per sub-lattice = the default; taps through L1 / L2) against the oracle:
+    config 5's size, and a size that is no multiple of any tile or step (partial sub-lattice tiles, the clamped taps of
+    every border).  Tolerance 1e-5 on the radiance (expf differs between the math libraries); pixels that depend on the
+    reference's out-of-bounds row H are excluded."""
+    w, h = size
+    scene = pkg.scenes.heightfield_scene((w, h), nx=257, nz=129)
+    flat = scene.build_scene()
+    with pkg.PathTracer(max_bounces=4) as pt:
+        pt.set_param("frames_in_flight", 1)
+        pt.create_buffers((w, h), flat)
+        pt.max_iterations = 2
+        for _ in range(2):
+            pt.path_trace(scene.camera)
+        g = {k: pt.download(k) for k in ("color", "normal", "depth")}
+        outs = []
+        for variant in (0, 1):
+            pt.set_param("denoise_variant", variant)
+            pt.denoise()
+            outs.append(pt.download("final"))
+    den, touched = orc.denoise(scene.camera, w, h, g["color"], g["normal"], g["depth"])
+    ok = ~touched
+    assert ok.mean() > 0.4
+    for variant, out in enumerate(outs):
+        err = float(np.max(np.abs(out[ok] - den[ok])))
+        assert err <= 1e-5, (variant, err)
+    assert float(np.max(np.abs(outs[0] - outs[1]))) <= 1e-5   # including the pixels the oracle leaves undefined
+
+
 def test_api_semantics(pkg, golden_dir):
     """max_iterations no-op, restart, iteration(), error codes -- PathTracer's observable behaviour."""
     scene, w, h = _golden_scenes(golden_dir)["spheres"]

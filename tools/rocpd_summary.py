@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (kernel trace) as a per-kernel table:
-   python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/xyz_kernel_stats.txt"""
+   python tools/rocpd_summary.py gpurun_out/prof/x_results.db [--by-grid] > profiles/xyz_kernel_stats.txt
+(--by-grid: one line per kernel and grid size, e.g. the four A-Trous passes)"""
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, by_grid=False):
     c = sqlite3.connect(path)
-    rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                     "max(vgpr_count), max(sgpr_count), max(lds_size), max(workgroup_x) from kernels group by name "
+    key = "name || ' grid ' || grid_x" if by_grid else "name"
+    rows = c.execute(f"select {key}, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+                     f"max(vgpr_count), max(sgpr_count), max(lds_size), max(workgroup_x) from kernels group by {key} "
                      "order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
     print(f"{'kernel':<70} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>10} {'%':>6} {'vgpr':>5} {'sgpr':>5} {'lds':>6} {'wg':>5}")
     for name, calls, tot, avg, mn, mx, vg, sg, lds, wg in rows:
-        short = name.split("(")[0][-70:]
+        short = (name.split("(")[0] + (name[name.rindex(" grid "):] if by_grid else ""))[-70:]
         print(f"{short:<70} {calls:>6} {tot / 1e6:>10.3f} {avg / 1e3:>10.2f} {mn / 1e3:>9.2f} {mx / 1e3:>10.2f} "
               f"{100.0 * tot / total:>6.2f} {vg:>5} {sg:>5} {lds:>6} {wg:>5}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], by_grid="--by-grid" in sys.argv[2:])
