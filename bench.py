@@ -177,6 +177,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         batch = args.batch_frames
     elif args.steps >= streams * 32:
         batch = 32
+    elif args.steps <= 32:
+        batch, streams = args.steps, 1      # one launch sequence carries them all (measured: 1 x 20 beats 2 x 10 and 4 x 5)
     else:
         batch = max(1, min(32, -(-args.steps // streams)))
 
@@ -365,8 +367,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                    "resolution": [W, H], "max_bounces": MB, "frames_in_flight": streams * batch,
                    "frames_per_launch": batch,
                    "schedule_note": ("tuned schedule (32 frames per launch)" if batch == 32 else
-                                     f"--steps {args.steps} is less than one round of full batches: {streams} launches of {batch} "
-                                     "frames; the tuned 32-frame schedule is reported under steady_state"),
+                                     f"--steps {args.steps} is less than one round of full batches: {streams} launch sequence(s) of "
+                                     f"{batch} frames; the tuned 32-frame schedule is reported under steady_state"),
                    "rays_per_step": round(rays / args.steps),
                    "live_per_bounce_last_frame_rank0": last_live, "exact_redo_rays": slow_rays,
                    "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks; "
