@@ -77,6 +77,7 @@ def parse():
                     help="frames traced per launch; 0 = 32, or an even split of --steps over the streams when --steps is "
                          "smaller than one round of full batches")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
+    ap.add_argument("--traverse-waves", type=int, default=0, help="persistent wavefronts of a full-size traversal launch (0 = tuned default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
     ap.add_argument("--gather", choices=("rccl", "ipc"), default="rccl",
@@ -188,7 +189,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.set_param("batch_frames", batch_frames)
         # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU; half of that for
         # the smaller launches of a rank among 4 or 8
-        pt.set_param("traverse_waves", 5120 if world <= 2 else 2560)
+        pt.set_param("traverse_waves", args.traverse_waves or (5120 if world <= 2 else 2560))
         pt.create_buffers((W, H), flat)
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
         if world > 1:

@@ -84,6 +84,8 @@ struct DScene {
   uint32_t force_slow;             // test hook: hand EVERY ray to the exact redo (redo_slow_rays)
   uint32_t static_eighths;         // persistent traversal: share (x/8) of each image region dealt without atomics
   uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle
+  uint32_t split_idle;             // ... and once the launch has no rays left: split busy lanes' stacks among idle ones when
+                                   // at least this many lanes are idle (0: never)
   float root_min[3];               // box of the root (tested before descending, like any inner node)
   float root_max[3];
   uint32_t root_ref;               // record 0, or kLeafBit for a single-triangle mesh

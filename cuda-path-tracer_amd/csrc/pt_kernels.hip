@@ -904,6 +904,11 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
                                                const DBatchInfo& bi)
 {
   __shared__ uint32_t s_stack[kLds4 * kWave];
+  // work splitting at the end of a launch (see `split` below): per lane = per ray group led by that lane
+  __shared__ unsigned long long s_grp_best[kWave];  // best candidate of the group so far: t bits << 32 | ~triangle
+  __shared__ uint32_t s_grp_count[kWave];           // lanes still walking for the group
+  __shared__ uint32_t s_leader[kWave];              // per lane: the lane that leads the ray it is walking for
+  __shared__ uint32_t s_pair[kWave];                // scratch: r-th donor of a split round
   // explicitly an LDS pointer: as a generic pointer the pop below compiles to a flat load
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   lds_u32* stack = (lds_u32*)s_stack + threadIdx.x;
@@ -929,7 +934,9 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   bool active = false;
   bool pending = false;
   uint32_t slot = 0u, cur = 0u, flags = 0u;
-  int sp = 0, best_k = -1;
+  int sp = 0, sbase = 0, best_k = -1;  // the lane's stack is entries [sbase, sp) of its column
+  bool split_mode = false;             // wave-uniform: some ray of this wavefront is walked by several lanes
+  uint32_t since_split = 0u;
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
   bool neg_x = false, neg_y = false, neg_z = false;  // sign of 1/d per axis: which plane of a box is the near one
@@ -954,7 +961,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     const int top = sp - 1;
     uint32_t r = stack[min(max(top, 0), lds_cap - 1) * kWave];
     if (__builtin_expect(top >= lds_cap, 0)) r = sc.spill[(size_t)(top - lds_cap) * sc.spill_stride + gid].x;
-    return top >= 0 ? r : kNoChild;
+    return top >= sbase ? r : kNoChild;
   };
   // the conservative slab pair of one box for this lane's ray, tolerance folded INWARDS: if even that interval is
   // non-empty, the reference's exact test of the box passes
@@ -1016,13 +1023,105 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
   };
 
+  // ---- work splitting: the tail of a launch -------------------------------------------------------------------
+  // When the launch has no rays left to hand out, a wavefront's lanes fall idle one by one while a few long rays
+  // (a ray grazing the terrain visits hundreds of nodes) keep the launch -- and the whole bounce behind it -- alive:
+  // 100-150 us per launch, whatever its size, which is most of the time of a small launch (a single frame, a rank's
+  // share of a multi-GPU frame, the late bounces).  An idle lane then takes the BOTTOM entry of a busy lane's stack
+  // (the farthest, usually largest pending subtree) together with a copy of its ray and walks it as a member of
+  // that ray's group.  Candidates are merged in LDS with a 64-bit minimum (t, then the reference's tie rule: the
+  // later triangle); the last member to finish writes the ray's result like an unsplit lane would.  The closest
+  // hit is the same whoever walks which subtree, so results do not change (tests: every schedule bit-identical).
+  auto candidate_key = [&]() -> unsigned long long {
+    return best_k >= 0 ? ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned long long)(~(uint32_t)best_k) : ~0ull;
+  };
+  auto adopt = [&](unsigned long long key) {
+    if (key != ~0ull) {
+      const float t = __uint_as_float((uint32_t)(key >> 32));
+      const int k = (int)~(uint32_t)key;
+      if (t < best_t || (t == best_t && k > best_k)) {
+        best_t = t;
+        best_k = k;
+        limit = scale * t * 1.001f;
+      }
+    }
+  };
+  // a lane whose walk has ended: alone -> finalize; in a group -> hand in the candidate, and finalize only as the last
+  auto retire = [&]() {
+    if (split_mode) {
+      const uint32_t leader = s_leader[threadIdx.x];
+      __hip_atomic_fetch_min(&s_grp_best[leader], candidate_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t left = __hip_atomic_fetch_sub(&s_grp_count[leader], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (left != 1u) return;  // another member is still walking: it will finish the ray
+      best_k = -1;
+      best_t = FLT_MAX;
+      adopt(__hip_atomic_load(&s_grp_best[leader], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    finalize();
+  };
+  auto split = [&]() {
+    // share what the members of a group know (tightens every member's culling limit)
+    if (split_mode && active) {
+      const uint32_t leader = s_leader[threadIdx.x];
+      const unsigned long long mine = candidate_key();
+      const unsigned long long seen = __hip_atomic_fetch_min(&s_grp_best[leader], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      adopt(seen);
+    }
+    const bool can_give = active && sp - sbase >= 1 && sbase < lds_cap;
+    const uint64_t donors = __ballot(can_give), takers = __ballot(!active);
+    const uint32_t pairs = min((uint32_t)__popcll(donors), (uint32_t)__popcll(takers));
+    if (pairs == 0u) return;
+    if (!split_mode) {  // first split of this wavefront: every lane leads its own ray
+      s_leader[threadIdx.x] = threadIdx.x;
+      s_grp_count[threadIdx.x] = active ? 1u : 0u;
+      s_grp_best[threadIdx.x] = ~0ull;
+      split_mode = true;
+    }
+    const uint32_t drank = rank_below(donors), trank = rank_below(takers);
+    if (can_give && drank < pairs) s_pair[drank] = threadIdx.x;
+    const bool take = !active && trank < pairs;
+    const uint32_t d = take ? s_pair[trank] : threadIdx.x;  // my donor (myself: no change)
+    // the donor's ray and walk state (every lane reads its partner's registers)
+    auto from = [&](float v) { return __shfl(v, (int)d, kWave); };
+    const f3 d_ro = mk3(from(ro.x), from(ro.y), from(ro.z)), d_rd = mk3(from(rd.x), from(rd.y), from(rd.z));
+    const f3 d_inv = mk3(from(inv.x), from(inv.y), from(inv.z));
+    const f3 d_oin = mk3(from(oin.x), from(oin.y), from(oin.z)), d_oif = mk3(from(oif.x), from(oif.y), from(oif.z));
+    const float d_tmin = from(tmin), d_best_t = from(best_t), d_scale = from(scale), d_limit = from(limit);
+    const int d_best_k = __shfl(best_k, (int)d, kWave), d_sbase = __shfl(sbase, (int)d, kWave);
+    const uint32_t d_slot = (uint32_t)__shfl((int)slot, (int)d, kWave);
+    if (take) {
+      ro = d_ro;
+      rd = d_rd;
+      inv = d_inv;
+      oin = d_oin;
+      oif = d_oif;
+      neg_x = inv.x < 0.0f;
+      neg_y = inv.y < 0.0f;
+      neg_z = inv.z < 0.0f;
+      tmin = d_tmin;
+      best_t = d_best_t;
+      best_k = d_best_k;
+      scale = d_scale;
+      limit = d_limit;
+      slot = d_slot;
+      cur = ((lds_u32*)s_stack)[d_sbase * kWave + (int)d];  // the bottom of the donor's stack
+      sp = sbase = 0;
+      ray_boxes = 0u;
+      const uint32_t leader = s_leader[d];
+      s_leader[threadIdx.x] = leader;
+      __hip_atomic_fetch_add(&s_grp_count[leader], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      active = true;
+    }
+    if (can_give && drank < pairs) ++sbase;
+  };
+
   for (;;) {
     const uint64_t idle_mask = __ballot(!active);
     const uint32_t idle = (uint32_t)__popcll(idle_mask);
     const bool more = priv_next < priv_end || !feed.exhausted();
     if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
       if (pending) {
-        finalize();
+        retire();
         pending = false;
       }
       if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
@@ -1085,18 +1184,31 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
             best_k = -1;
             limit = scale * best_t * 1.001f;
             cur = sc.bvh4_root;
-            sp = 0;
+            sp = sbase = 0;
             ray_boxes = 0u;
+            if (split_mode) {  // (only when rays are still handed out after a split: never in practice)
+              s_leader[threadIdx.x] = threadIdx.x;
+              s_grp_count[threadIdx.x] = 1u;
+              s_grp_best[threadIdx.x] = ~0ull;
+            }
           }
         }
         if (go) active = true;
         else if (kFirst && !wrote) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
       }
+    } else if (!more && sc.split_idle != 0u && idle >= sc.split_idle && ++since_split >= 4u) {
+      // nothing left to fetch: idle lanes help the busy ones (at most every fourth iteration)
+      since_split = 0u;
+      if (pending) {
+        retire();
+        pending = false;
+      }
+      split();
     }
     if (__ballot(active) == 0ull) {
       if (priv_next >= priv_end && feed.exhausted()) {
         if (pending) {
-          finalize();
+          retire();
           pending = false;
         }
         break;
@@ -1200,7 +1312,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           cur = ref[0];
         } else {  // nothing was pushed: `below` is still the top
           cur = below;
-          sp = sp > 0 ? sp - 1 : 0;
+          sp = max(sp - 1, sbase);
         }
       } else {
         // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
@@ -1247,7 +1359,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         }
 #endif
         cur = below;
-        sp = sp > 0 ? sp - 1 : 0;
+        sp = max(sp - 1, sbase);
       }
       if (cur == kNoChild) {
         active = false;

@@ -82,6 +82,8 @@ struct ptc_ctx {
     DFrame stage{};
     DeviceCounters* counters = nullptr;  // one per frame of the batch
     hipEvent_t done = nullptr;  // after this slot's last accumulate
+    uint32_t* live_host = nullptr;  // pinned: live[] of the slot's last batch (frame 0), copied back after `done`
+    bool live_pending = false;      // ... and not yet looked at (launch sizing, see traverse_waves_for)
     int cur = 0;
     int work_slot = 0;
     int bounces_done = 0;
@@ -158,6 +160,12 @@ struct ptc_ctx {
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
+  uint32_t split_idle = 8;    // "split_idle"
+  uint32_t min_waves = 1024;  // "min_waves": fewest persistent wavefronts of a traversal launch
+  // live paths entering each bounce of one recent frame (what a frame of this scene / camera looks like): the host
+  // never waits for them, they only size the traversal launches
+  uint32_t est_live[kMaxBounces + 1] = {};
+  bool est_valid = false;
   int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2
   uint32_t lds_entries = 24;  // == kLds4 in pt_kernels.hip (PT_T4_LDS); fewer only through "debug_lds_entries"
   int force_slow = 0;
@@ -326,11 +334,13 @@ void free_slots(ptc_ctx* ctx)
   for (auto& sl : ctx->slots) {
     if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
     if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.live_host) (void)hipHostFree(sl.live_host);
     if (sl.spill) (void)hipFree(sl.spill);
   }
   ctx->slots.clear();
   ctx->pending.clear();
   ctx->active_slot = -1;
+  ctx->est_valid = false;
 }
 
 }  // namespace
@@ -529,6 +539,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.bvh4_root = w4.root_ref;
   d.dummy_ref = w4.dummy_ref;
   d.refill_lanes = ctx->refill_lanes;
+  d.split_idle = ctx->split_idle;
   d.static_eighths = ctx->static_eighths;
   d.force_slow = (uint32_t)ctx->force_slow;
   d.spill = nullptr;
@@ -634,6 +645,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
       sl.own_stream = true;
     }
     HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.live_host), sizeof(uint32_t) * (kMaxBounces + 1), hipHostMallocDefault));
     const size_t BP = (size_t)B * P;  // frame f of the batch at element offset f * P (DBatchInfo::stride)
     for (int k = 0; k < 2; ++k) {
       if (int rc = dev_alloc(ctx, pool, &sl.paths[k].o4, BP)) return rc;
@@ -798,6 +810,17 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->scene.static_eighths = ctx->static_eighths;
     return PTC_OK;
   }
+  if (std::strcmp(name, "min_waves") == 0) {
+    if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "min_waves out of range");
+    ctx->min_waves = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "split_idle") == 0) {
+    if (value < 0 || value > 64) return fail(ctx, PTC_ERR_INVALID, "split_idle must be in [0,64]");
+    ctx->split_idle = (uint32_t)value;
+    ctx->scene.split_idle = ctx->split_idle;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "refill_lanes") == 0) {
     if (value < 1 || value > 64) return fail(ctx, PTC_ERR_INVALID, "refill_lanes must be in [1,64]");
     ctx->refill_lanes = (uint32_t)value;
@@ -842,6 +865,30 @@ static int frame_ready(ptc_ctx* ctx)
 }
 
 namespace {
+
+// Persistent wavefronts of a traversal launch.  A launch ends with its longest ray (about 100 us however few rays it
+// carries), so a small launch wants about one ray per lane -- rays / 64 wavefronts, at least 1024, at most 3072 -- and
+// only a launch with eight or more rays per lane fills every wavefront slot of the chip (traverse_waves: what is
+// resident at five per SIMD).  Measured on single 1080p frames (2 M rays at the first bounce, 65 k at the eighth): one size
+// for all bounces 2.60 ms per frame, sized per bounce 2.1 ms.  The ray count of a bounce lives on the device; the
+// host sizes with the counts of a recent frame (FrameSlot::live_host), a bounce it knows nothing about with its cap.
+uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce)
+{
+  for (auto& sl : ctx->slots)
+    if (sl.live_pending && sl.done && hipEventQuery(sl.done) == hipSuccess) {
+      std::memcpy(ctx->est_live, sl.live_host, sizeof ctx->est_live);
+      ctx->est_valid = true;
+      sl.live_pending = false;
+    }
+  (void)hipGetLastError();  // hipEventQuery's "not ready" is no error
+  uint64_t per_frame = ctx->pix_count;
+  if (ctx->est_valid && ctx->est_live[0] == ctx->pix_count) per_frame = std::min<uint64_t>(ctx->pix_count, ctx->est_live[bounce]);
+  const uint64_t rays = per_frame * frames;
+  // (fewer than eight rays per lane at full size: 3072 wavefronts do as well or a little better -- single frames)
+  const uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * 8u ? ctx->traverse_waves : std::min<uint32_t>(ctx->traverse_waves, 3072u);
+  const uint64_t want = ((rays + kWave - 1u) / kWave + 7u) & ~7ull;
+  return (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(std::min<uint32_t>(ctx->min_waves, ctx->traverse_waves), want));
+}
 
 // Enqueue raygen for `count` consecutive iterations on the next slot (round robin) and make it the active batch.
 int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
@@ -924,11 +971,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       }
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
       if (int rc = timed_begin(tl)) return rc;
-      // persistent wavefronts for this launch: about 48 ray batches of 64 per wavefront at the first bounce (a
-      // wavefront that gets only a few batches spends its life draining), at least 1024, at most the
-      // configured number (what is resident; the stack overflow areas are sized for it)
-      const uint64_t rays0 = (uint64_t)sl.bi.count * ctx->pix_count;
-      const uint32_t waves = (uint32_t)std::min<uint64_t>(ctx->traverse_waves, std::max<uint64_t>(1024u, (rays0 / 3072u + 7u) & ~7ull));
+      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
       launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
                       sl.slow_list, sl.bi);
       wrote = true;
@@ -964,6 +1007,11 @@ int batch_end(ptc_ctx* ctx)
     if (int rc = check_last(ctx, "accumulate")) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->order_event, sl.stream));
     ctx->order_valid = true;
+  }
+  // the live counts of this batch's first frame, for the sizing of later launches (nobody waits for the copy)
+  if (sl.live_host && sl.bounces_done == ctx->max_bounces) {
+    HIP_TRY(ctx, hipMemcpyAsync(sl.live_host, &sl.counters[0].live[0], sizeof(uint32_t) * (kMaxBounces + 1), hipMemcpyDeviceToHost, sl.stream));
+    sl.live_pending = true;
   }
   HIP_TRY(ctx, hipEventRecord(sl.done, sl.stream));
   ctx->last_slot = ctx->active_slot;

@@ -224,6 +224,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "slot_offset"      added to every compacted slot index before the material RNG is seeded (path_tracer.cu:300).  A
  *                      rank of a multi-GPU run that numbers its paths locally (ptc_set_interleave) sets rank * (pixels of
  *                      the largest share) so that no two ranks draw the same random streams; 0 (default) = the reference
+ *   "split_idle"       once a traversal launch has handed out its last ray: idle lanes of a persistent wavefront that
+ *                      trigger work splitting (an idle lane takes over the bottom of a busy lane's traversal stack
+ *                      with a copy of its ray; default 8, 0 = never).  Cuts the latency tail of every launch
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 3 = 3/8)
  *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small
