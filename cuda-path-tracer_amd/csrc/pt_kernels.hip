@@ -35,6 +35,35 @@ __device__ __forceinline__ uint32_t rank_below(uint64_t mask)
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+// Path state, hit records and framebuffers stream through the chip once per kernel (hundreds of MB per frame), next to
+// a BVH working set (75 MB of nodes and triangles at 1M triangles) that every ray re-reads and that should own the
+// 4 MB L2 of its XCD: streaming accesses are marked non-temporal.
+#ifndef PT_NT
+#define PT_NT 1
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt(const float4* p)
+{
+#if PT_NT
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void stnt(float4* p, const float4 v)
+{
+#if PT_NT
+  v4f w;
+  w.x = v.x;
+  w.y = v.y;
+  w.z = v.z;
+  w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<v4f*>(p));
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 
 struct Ray {
@@ -571,21 +600,21 @@ __device__ __forceinline__ float running_mean(uint32_t iteration, float old_v, f
 }
 __device__ __forceinline__ void accumulate_color(float4* color4, uint32_t local_pixel, uint32_t iteration, f3 c)
 {
-  float4 old = iteration == 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : color4[local_pixel];
+  float4 old = iteration == 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : ldnt(&color4[local_pixel]);
   old.x = running_mean(iteration, old.x, c.x);
   old.y = running_mean(iteration, old.y, c.y);
   old.z = running_mean(iteration, old.z, c.z);
   old.w = 0.0f;
-  color4[local_pixel] = old;
+  stnt(&color4[local_pixel], old);
 }
 __device__ __forceinline__ void accumulate_nd(float4* nd4, uint32_t local_pixel, uint32_t iteration, f3 n, float depth)
 {
-  float4 old = iteration == 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : nd4[local_pixel];
+  float4 old = iteration == 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : ldnt(&nd4[local_pixel]);
   old.x = running_mean(iteration, old.x, n.x);
   old.y = running_mean(iteration, old.y, n.y);
   old.z = running_mean(iteration, old.z, n.z);
   old.w = running_mean(iteration, old.w, depth);
-  nd4[local_pixel] = old;
+  stnt(&nd4[local_pixel], old);
 }
 
 // generate_ray, ray_gen.cu:34-61 (frame invariants hoisted into DCamera)
@@ -628,15 +657,15 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
   const float fy = (float)y + rng.uniform();
   f3 o, d;
   generate_ray(cam, fx, fy, o, d);
-  paths.o4[s] = make_float4(o.x, o.y, o.z, __uint_as_float(pixel));
-  paths.d4[s] = make_float4(d.x, d.y, d.z, 0.0f);
-  paths.t4[s] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+  stnt(&paths.o4[s], make_float4(o.x, o.y, o.z, __uint_as_float(pixel)));
+  stnt(&paths.d4[s], make_float4(d.x, d.y, d.z, 0.0f));
+  stnt(&paths.t4[s], make_float4(1.0f, 1.0f, 1.0f, 0.0f));
 }
 
 __device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
 {
-  const float4 o = paths.o4[s];
-  const float4 d = paths.d4[s];
+  const float4 o = ldnt(&paths.o4[s]);
+  const float4 d = ldnt(&paths.d4[s]);
   Ray r;
   r.o = xyz(o);
   r.d = xyz(d);
@@ -664,8 +693,8 @@ __global__ __launch_bounds__(kWave) void k_trace(DScene sc, DPaths paths, DHits 
     rec.mat = 0u;
     rec.side = 0u;
     hit = ray_scene<kCount>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
-    hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
-    hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+    stnt(&hits.tp[s], make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z));
+    stnt(&hits.nm[s], make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31))));
     if (flags) atomicOr(&counters->flags, flags);
   }
   if (kCount) flush_tally(tally, counters, bounce, true);
@@ -696,8 +725,8 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
     rec.mat = 0u;
     rec.side = 0u;
     hit = ray_scene_wide<kCount>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
-    hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
-    hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+    stnt(&hits.tp[s], make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z));
+    stnt(&hits.nm[s], make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31))));
     if (flags) atomicOr(&counters->flags, flags);
   }
   if (kCount) flush_tally(tally, counters, bounce, true);
@@ -753,8 +782,8 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
 }
 __device__ __forceinline__ void store_hit(const DHits& hits, uint32_t slot, const Hit& rec)
 {
-  hits.tp[slot] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
-  hits.nm[slot] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+  stnt(&hits.tp[slot], make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z));
+  stnt(&hits.nm[slot], make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31))));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1015,10 +1044,10 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       const f3 p = ro + rd * best_t;
       const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
       const f3 nn = side == 0u ? outward : -outward;
-      hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
-      hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+      stnt(&hits.tp[slot], make_float4(best_t, p.x, p.y, p.z));
+      stnt(&hits.nm[slot], make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31))));
     } else if (kFirst && best_k == -1) {
-      hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
     }
     if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
   };
@@ -1130,14 +1159,14 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       priv_next = min(priv_end, priv_next + idle);
       if (!active && mine < range_end) {
         slot = mine;
-        const float4 o4 = paths.o4[slot];
-        const float4 d4 = paths.d4[slot];
+        const float4 o4 = ldnt(&paths.o4[slot]);
+        const float4 d4 = ldnt(&paths.d4[slot]);
         ro = xyz(o4);
         rd = xyz(d4);
         tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
         float t_in = FLT_MAX;
         if (!kFirst) {
-          const float carried = hits.tp[slot].x;
+          const float carried = ldnt(&hits.tp[slot]).x;
           if (carried >= 0.0f) t_in = carried;
         }
         bool go = sc.bvh_node_count != 0u;
@@ -1194,7 +1223,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           }
         }
         if (go) active = true;
-        else if (kFirst && !wrote) hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+        else if (kFirst && !wrote) stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
       }
     } else if (!more && sc.split_idle != 0u && idle >= sc.split_idle && ++since_split >= 4u) {
       // nothing left to fetch: idle lanes help the busy ones (at most every fourth iteration)
@@ -1391,7 +1420,7 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
     const uint32_t slot = __hip_atomic_load(&slow_list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Ray ray = load_ray(paths, slot);
     if (!kFirst) {
-      const float carried = hits.tp[slot].x;
+      const float carried = ldnt(&hits.tp[slot]).x;
       if (carried >= 0.0f) ray.tmax = carried;
     }
     float best_t = ray.tmax;
@@ -1406,10 +1435,10 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
       const f3 p = ray.o + ray.d * best_t;
       const uint32_t side = dot(ray.d, outward) < 0.0f ? 0u : 1u;
       const f3 nn = side == 0u ? outward : -outward;
-      hits.tp[slot] = make_float4(best_t, p.x, p.y, p.z);
-      hits.nm[slot] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31)));
+      stnt(&hits.tp[slot], make_float4(best_t, p.x, p.y, p.z));
+      stnt(&hits.nm[slot], make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31))));
     } else if (kFirst) {
-      hits.tp[slot] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+      stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
     }
   }
   if (flags) atomicOr(&counters->flags, flags);
@@ -1459,14 +1488,14 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   if (s >= n) return;
   Ray ray = load_ray(paths, s);
   if (!kFirst) {
-    const float carried = hits.tp[s].x;
+    const float carried = ldnt(&hits.tp[s]).x;
     if (carried >= 0.0f) ray.tmax = carried;
   }
   Hit rec;
   bool changed = false;
   sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
   if (changed) store_hit(hits, s, rec);
-  else if (kFirst) hits.tp[s] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+  else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
 }
 
 // The end of a bounce's closest-hit stage: the sphere run that ends the object list (if any) and the live count of
@@ -1494,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_tail_count(DScene sc, uint32_t obj_begi
   bool hit = false;
   if (s < n) {
     float t_so_far = -1.0f;
-    if (!kFirst) t_so_far = hits.tp[s].x;
+    if (!kFirst) t_so_far = ldnt(&hits.tp[s]).x;
     hit = t_so_far >= 0.0f;
     if (kSpheres) {
       Ray ray = load_ray(paths, s);
@@ -1506,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_tail_count(DScene sc, uint32_t obj_begi
         store_hit(hits, s, rec);
         hit = true;
       } else if (kFirst) {
-        hits.tp[s] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+        stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
       }
     }
   }
@@ -1591,10 +1620,10 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), color = mk3(0, 0, 0);
   uint32_t pixbits = 0u;
   if (active) {
-    const float4 o4 = in.o4[s];
-    const float4 d4 = in.d4[s];
-    const float4 t4 = in.t4[s];
-    const float4 tp = hits.tp[s];
+    const float4 o4 = ldnt(&in.o4[s]);
+    const float4 d4 = ldnt(&in.d4[s]);
+    const float4 t4 = ldnt(&in.t4[s]);
+    const float4 tp = ldnt(&hits.tp[s]);
     ro = xyz(o4);
     rd = xyz(d4);
     color = xyz(t4);
@@ -1609,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
       if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, -rd, 1e6f);  // raygen defaults, ray_gen.cu:26-28
       accumulate_color(fb.color4, local_pixel, acc_iteration, color);
     } else {
-      const float4 nm = hits.nm[s];
+      const float4 nm = ldnt(&hits.nm[s]);
       const f3 hn = xyz(nm);
       if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, hn, tp.x);  // path_tracer.cu:308-311
       const uint32_t ms = __float_as_uint(nm.w);
@@ -1632,9 +1661,9 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   const uint64_t live = __ballot(survives);
   if (survives) {
     const uint32_t dst = chunk_offsets[s / kChunk] + rank_below(live);
-    out.o4[dst] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixbits));
-    out.d4[dst] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-    out.t4[dst] = make_float4(color.x, color.y, color.z, 0.0f);
+    stnt(&out.o4[dst], make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixbits)));
+    stnt(&out.d4[dst], make_float4(rd.x, rd.y, rd.z, 0.0f));
+    stnt(&out.t4[dst], make_float4(color.x, color.y, color.z, 0.0f));
   }
 }
 
@@ -1646,7 +1675,7 @@ __global__ __launch_bounds__(256) void k_accumulate(DFrame stage, DFrame fb, uin
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= pix_count) return;
   for (uint32_t f = 0; f < bi.count; ++f) {
-    const float4 c = stage.color4[(size_t)f * bi.stride + i], g = stage.nd4[(size_t)f * bi.stride + i];
+    const float4 c = ldnt(&stage.color4[(size_t)f * bi.stride + i]), g = ldnt(&stage.nd4[(size_t)f * bi.stride + i]);
     accumulate_color(fb.color4, i, bi.iteration[f], mk3(c.x, c.y, c.z));
     accumulate_nd(fb.nd4, i, bi.iteration[f], mk3(g.x, g.y, g.z), g.w);
   }
@@ -1729,8 +1758,8 @@ __global__ __launch_bounds__(kWave) void k_intersect(DScene sc, const float4* ra
   Tally tally;
   const bool hit = kVariant == 0 ? ray_scene<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally)
                                  : ray_scene_wide<false>(ray, sc, rec, s_stack + threadIdx.x, flags, tally);
-  hits.tp[s] = make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z);
-  hits.nm[s] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+  stnt(&hits.tp[s], make_float4(hit ? rec.t : -1.0f, rec.p.x, rec.p.y, rec.p.z));
+  stnt(&hits.nm[s], make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31))));
   if (flags) atomicOr(&counters->flags, flags);
 }
 
