@@ -78,6 +78,7 @@ def parse():
                          "smaller than one round of full batches")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
     ap.add_argument("--traverse-waves", type=int, default=0, help="persistent wavefronts of a full-size traversal launch (0 = tuned default)")
+    ap.add_argument("--ray-sort", type=int, default=0, help="1: direction-octant ray sorting of the pick-up order (config.ray_sort)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
     ap.add_argument("--gather", choices=("rccl", "ipc"), default="rccl",
@@ -190,6 +191,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU; half of that for
         # the smaller launches of a rank among 4 or 8
         pt.set_param("traverse_waves", args.traverse_waves or (5120 if world <= 2 else 2560))
+        pt.set_param("ray_sort", args.ray_sort)
         pt.create_buffers((W, H), flat)
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
         if world > 1:
@@ -366,7 +368,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                                f"{W}x{H}, {MB} bounces, 1 spp/step, streaming mode",
                    "triangles": len(flat.indices) // 3, "bvh_nodes": int(len(flat.bvh)), "bvh_depth": int(bvh_depth),
                    "resolution": [W, H], "max_bounces": MB, "frames_in_flight": streams * batch,
-                   "frames_per_launch": batch,
+                   "frames_per_launch": batch, "ray_sort": args.ray_sort,
                    "schedule_note": ("tuned schedule (32 frames per launch)" if batch == 32 else
                                      f"--steps {args.steps} is less than one round of full batches: {streams} launch sequence(s) of "
                                      f"{batch} frames; the tuned 32-frame schedule is reported under steady_state"),

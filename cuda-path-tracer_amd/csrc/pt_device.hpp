@@ -207,7 +207,11 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                     uint32_t* slow_list, const DBatchInfo& bi);
+                     uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi);
+// coherence sort of the pick-up order (never of the slots): octs = direction octant per slot (written by launch_shade
+// when given), order = per block of 4096 slots the slots grouped by octant; launch_traverse reads its rays through it
+void launch_sort_octant(hipStream_t s, const uint8_t* octs, uint32_t* order, uint32_t max_paths, int bounce,
+                        DeviceCounters* counters, const DBatchInfo& bi);
 void launch_tail_count(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                        DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts, DeviceCounters* counters,
                        const DBatchInfo& bi);
@@ -215,7 +219,8 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
                  DeviceCounters* counters, const DBatchInfo& bi);
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
                   bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
-                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, const DBatchInfo& bi);
+                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, uint8_t* octs,
+                  const DBatchInfo& bi);
 void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi);
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);

@@ -930,7 +930,7 @@ __device__ __forceinline__ void set_aside(DeviceCounters* counters, uint32_t* sl
 template <bool kCount, bool kFirst>
 __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
                                                int bounce, int work_slot, DeviceCounters* counters, uint32_t* slow_list,
-                                               const DBatchInfo& bi)
+                                               const uint32_t* order, const DBatchInfo& bi)
 {
   __shared__ uint32_t s_stack[kLds4 * kWave];
   // work splitting at the end of a launch (see `split` below): per lane = per ray group led by that lane
@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       const uint32_t range_end = priv_end;
       priv_next = min(priv_end, priv_next + idle);
       if (!active && mine < range_end) {
-        slot = mine;
+        slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
         const float4 o4 = ldnt(&paths.o4[slot]);
         const float4 d4 = ldnt(&paths.d4[slot]);
         ro = xyz(o4);
@@ -1447,9 +1447,9 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
 template <bool kCount, bool kFirst>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES)))
 void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce, int work_slot,
-                 DeviceCounters* counters, uint32_t* slow_list, DBatchInfo bi)
+                 DeviceCounters* counters, uint32_t* slow_list, const uint32_t* order, DBatchInfo bi)
 {
-  traverse4_walk<kCount, kFirst>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+  traverse4_walk<kCount, kFirst>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
   // Epilogue: every wavefront signs off; the last one redoes the rays that were set aside.  The list entries were
   // written with agent-scope atomic stores; waiting for this wavefront's own stores before the sign-off and reading
   // the list with agent-scope loads orders them without a full L2 write-back per wavefront.
@@ -1593,11 +1593,12 @@ __global__ __launch_bounds__(1024) void k_scan(int bounce, int last_bounce, cons
 // straight into `fb`.
 __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out, DHits hits, int staged, int bounce,
                                                int last_bounce, const uint32_t* slot_base, const uint32_t* chunk_offsets,
-                                               DFrame fb, DBand band, DeviceCounters* counters, DBatchInfo bi)
+                                               DFrame fb, DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi)
 {
   const uint32_t frame = blockIdx.y;  // see DBatchInfo
   const uint32_t iteration = bi.iteration[frame];
   const uint32_t acc_iteration = staged ? 0u : iteration;
+  if (octs) octs += (size_t)frame * bi.stride;
   in.o4 += (size_t)frame * bi.stride;
   in.d4 += (size_t)frame * bi.stride;
   in.t4 += (size_t)frame * bi.stride;
@@ -1664,6 +1665,56 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
     stnt(&out.o4[dst], make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixbits)));
     stnt(&out.d4[dst], make_float4(rd.x, rd.y, rd.z, 0.0f));
     stnt(&out.t4[dst], make_float4(color.x, color.y, color.z, 0.0f));
+    // direction octant of the new ray, for the coherence sort of the next bounce (k_sort_octant)
+    if (octs) octs[dst] = (uint8_t)((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u));
+  }
+}
+
+// Ray sorting ("ray_sort", BASELINE.json's ray-sorted wavefront; the reference keeps a sort_by_key by material
+// commented out, path_tracer.cu:439-446).  The slots -- and with them the random numbers, which are keyed on the
+// compacted slot index -- are NOT permuted: what is sorted is the ORDER in which the persistent traversal lanes pick
+// their rays up.  Within every block of 4096 consecutive slots (neighbouring pixels: neighbouring ray origins) the
+// rays are grouped by direction octant, stably, into an index array the ray feed reads through; a wavefront's 64 rays
+// then start close together AND head the same way.  Results cannot change; what it buys is measured in DESIGN.md.
+constexpr uint32_t kSortBlock = 4096u;
+__global__ __launch_bounds__(1024) void k_sort_octant(const uint8_t* octs, uint32_t* order, int bounce, DeviceCounters* counters,
+                                                      DBatchInfo bi)
+{
+  __shared__ uint32_t s_cnt[8][4][16];  // [octant][round][wavefront]
+  __shared__ uint32_t s_base[8][4][16];
+  const uint32_t frame = blockIdx.y;
+  const uint32_t n = counters[frame].live[bounce];
+  const uint32_t block0 = blockIdx.x * kSortBlock;
+  if (block0 >= n) return;
+  const size_t fbase = (size_t)frame * bi.stride;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t oct[4], rank[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t s = block0 + (uint32_t)r * 1024u + threadIdx.x;
+    oct[r] = s < n ? (uint32_t)octs[fbase + s] : 8u;
+#pragma unroll
+    for (uint32_t o = 0; o < 8u; ++o) {
+      const uint64_t m = __ballot(oct[r] == o);
+      if (oct[r] == o) rank[r] = rank_below(m);
+      if (lane == 0u) s_cnt[o][r][wave] = (uint32_t)__popcll(m);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0u) {  // 512 counters: exclusive scan in (octant, round, wavefront) order
+    uint32_t run = 0u;
+    for (int o = 0; o < 8; ++o)
+      for (int r = 0; r < 4; ++r)
+        for (int w = 0; w < 16; ++w) {
+          s_base[o][r][w] = run;
+          run += s_cnt[o][r][w];
+        }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t s = block0 + (uint32_t)r * 1024u + threadIdx.x;
+    if (oct[r] < 8u) order[fbase + block0 + s_base[oct[r]][r][wave] + rank[r]] = (uint32_t)fbase + s;
   }
 }
 
@@ -2111,23 +2162,29 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                     uint32_t* slow_list, const DBatchInfo& bi)
+                     uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi)
 {
   const dim3 grid(waves), block(kWave);
   if (count_tests) {
-    if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-    else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+    if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
   } else {
-    if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-    else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+    if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
   }
 }
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,
                   bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
-                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, const DBatchInfo& bi)
+                  const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, uint8_t* octs,
+                  const DBatchInfo& bi)
 {
   hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u), bi.count), dim3(256), 0, s, scene, in, out, hits,
-                     staged ? 1 : 0, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, band, counters, bi);
+                     staged ? 1 : 0, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, band, counters, octs, bi);
+}
+void launch_sort_octant(hipStream_t s, const uint8_t* octs, uint32_t* order, uint32_t max_paths, int bounce,
+                        DeviceCounters* counters, const DBatchInfo& bi)
+{
+  hipLaunchKernelGGL(k_sort_octant, dim3(div_up(max_paths, kSortBlock), bi.count), dim3(1024), 0, s, octs, order, bounce, counters, bi);
 }
 void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi)
 {

@@ -77,6 +77,8 @@ struct ptc_ctx {
     uint32_t* chunk_offsets = nullptr;
     uint32_t* slow_list = nullptr;  // slots of rays set aside for the exact redo at the end of a traversal launch
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
+    uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
+    uint32_t* order = nullptr;      // ... and the order in which the traversal lanes pick them up
     uint2* spill = nullptr;         // traversal stack overflow area of this slot's launches (DScene::spill)
     size_t spill_elems = 0;
     DFrame stage{};
@@ -166,6 +168,7 @@ struct ptc_ctx {
   // never waits for them, they only size the traversal launches
   uint32_t est_live[kMaxBounces + 1] = {};
   bool est_valid = false;
+  int ray_sort = 0;           // "ray_sort": 1 = traversal lanes pick their rays up grouped by direction octant (bounces >= 1)
   int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2
   uint32_t lds_entries = 24;  // == kLds4 in pt_kernels.hip (PT_T4_LDS); fewer only through "debug_lds_entries"
   int force_slow = 0;
@@ -658,6 +661,10 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, (size_t)B * chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_stack, (size_t)kStackDepth * kWave)) return rc;
+    if (ctx->ray_sort) {
+      if (int rc = dev_alloc(ctx, pool, &sl.octs, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.order, BP)) return rc;
+    }
     if (int rc = dev_alloc(ctx, pool, &sl.counters, (size_t)B)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(sl.counters, 0, sizeof(DeviceCounters) * (size_t)B, ctx->stream));
     sl.bi = DBatchInfo{};
@@ -827,6 +834,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->scene.refill_lanes = ctx->refill_lanes;
     return PTC_OK;
   }
+  if (std::strcmp(name, "ray_sort") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "ray_sort must be 0 or 1");
+    if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set ray_sort before ptc_resize");
+    ctx->ray_sort = value;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "denoise_variant") == 0) {
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "denoise_variant must be 0 or 1");
     ctx->denoise_variant = value;
@@ -956,6 +969,9 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     return PTC_OK;
   };
   bool wrote = false;  // some launch of this bounce has written the hit records
+  // ray sorting: the shade kernel of the previous bounce has tagged its surviving rays with their direction octant
+  const bool sorted = ctx->ray_sort && ctx->trace_variant == 3 && bounce >= 1 && sl.order && !ctx->launches.empty();
+  if (sorted) launch_sort_octant(sl.stream, sl.octs, sl.order, ctx->pix_count, bounce, sl.counters, sl.bi);
   if (ctx->trace_variant == 3) {
     // closest hit = the object list walked by the launches of TraceLaunch
     for (size_t k = 0; k < ctx->launches.size(); ++k) {
@@ -973,7 +989,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       if (int rc = timed_begin(tl)) return rc;
       const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
       launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
-                      sl.slow_list, sl.bi);
+                      sl.slow_list, sorted ? sl.order : nullptr, sl.bi);
       wrote = true;
       if (int rc = timed_end(tl)) return rc;
     }
@@ -990,7 +1006,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
                     bounce, sl.chunk_counts, sl.counters, sl.bi);
   launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
   launch_shade(sl.stream, scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
-               sl.chunk_offsets, sl.stage, ctx->band, sl.counters, sl.bi);
+               sl.chunk_offsets, sl.stage, ctx->band, sl.counters, ctx->ray_sort && !last ? sl.octs : nullptr, sl.bi);
   sl.cur ^= 1;
   sl.bounces_done = bounce + 1;
   return check_last(ctx, "bounce");
@@ -1591,7 +1607,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
         const auto& l = ctx->launches[k];
         if (l.pre_begin < l.pre_end)
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
-        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, bi);
+        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr, bi);
       }
       launch_tail_count(ctx->stream, scene, ctx->tail_begin, ctx->tail_end, false, paths, hits, n, 0, chunk_counts, counters, bi);
       e = hipGetLastError();

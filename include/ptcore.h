@@ -218,6 +218,11 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   A batch of a single iteration (an interactive front-end that presents or denoises after every iteration, the
  *   stepwise calls) runs in one of eight extra one-frame slots with streams of their own, so that viewer-style
  *   use keeps eight frames in flight as well (config 5, 1 spp + denoise per 1080p frame: 1.6 ms)
+ *   "ray_sort"         1: from the second bounce on, the persistent traversal lanes pick their rays up grouped by
+ *                      direction octant within blocks of 4096 neighbouring slots (an index array built by a small
+ *                      kernel per bounce; the slots themselves, and so the random numbers, stay where they are).
+ *                      Default 0: measured on the benchmark scene it does not pay for itself.  Before
+ *                      ptc_resize
  *   "denoise_variant"  0 (default): the A-Trous passes stage their taps in LDS, one sub-lattice of the dilated filter per
  *                      workgroup; 1: taps through L1 / L2 (round-1 kernel, kept as a cross-check).  Same results up to
  *                      summation order (both within 1e-5 of the oracle)

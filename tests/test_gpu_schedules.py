@@ -58,6 +58,10 @@ def test_every_schedule_matches_reference_order_and_oracle(pkg, orc, small_scene
         for fif in (1, 3):
             got = frames(pkg, scene, flat, w, h, 3, 8, variant=variant, fif=fif)
             assert same(got, base), (variant, fif)
+    # ray sorting: the traversal lanes pick their rays up grouped by direction octant -- same rays, same slots
+    for fif, batch in ((1, 1), (6, 3)):
+        got = frames(pkg, scene, flat, w, h, 3, 8, fif=fif, params=(("batch_frames", batch), ("ray_sort", 1)))
+        assert same(got, base), ("ray_sort", fif, batch)
     # the default walk with only two stack entries per lane in LDS: everything deeper goes through the global
     # overflow area (push, peek and pop on both sides of the boundary)
     for fif, batch in ((1, 1), (6, 3)):
@@ -267,7 +271,8 @@ def test_benchmark_size_against_oracle(pkg, orc, big):
     scene, flat, depth = big
     sh = orc.SceneHandle(flat)
     ref = orc.render_streaming(flat, scene.camera, 1920, 1080, 0, 2, 8, scene_handle=sh)
-    for params in ((), (("frames_in_flight", 1),), (("frames_in_flight", 2), ("batch_frames", 1), ("debug_lds_entries", 8))):
+    for params in ((), (("frames_in_flight", 1),), (("frames_in_flight", 2), ("batch_frames", 1), ("debug_lds_entries", 8)),
+                   (("frames_in_flight", 4), ("batch_frames", 2), ("ray_sort", 1))):
         got = frames(pkg, scene, flat, 1920, 1080, 2, 8, params=params)
         err = float(np.mean(np.sum((got["color"].astype(np.float64) - ref["color"]) ** 2, axis=-1)))
         assert err < 1e-4, (params, err)                       # the stated tolerance ...
