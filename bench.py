@@ -150,7 +150,7 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
     }
     sq = pmc_record("pmc_sq_%d.json", frames_per_launch)
     if sq is not None:
-        roof["valu"] = {k: sq.get(k) for k in ("valu_busy_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
+        roof["valu"] = {k: sq.get(k) for k in ("valu_busy_frac", "valu_pipe_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
                                                 "salu_inst_per_ray", "l2_hit_frac", "wave_occupancy_frac", "frames_per_launch",
                                                 "matches_this_run", "source")}
     return roof

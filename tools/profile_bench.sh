@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras "$@" > "$OUT/bench.log" 2>&1
 rc=$?
 cd "$ROOT"
-python3 tools/rocpd_summary.py "$(ls "$OUT"/prof/*.db | head -1)" $SUMMARY_FLAGS > "$OUT/kernel_stats.txt" 2>&1
+python3 tools/rocpd_summary.py "$(ls "$OUT"/prof/*.db | head -1)" $SUMMARY_FLAGS --tail "k_traverse4<false:8" > "$OUT/kernel_stats.txt" 2>&1
 rm -rf "$OUT/prof"
 tail -c 2500 "$OUT/bench.log"; echo; cat "$OUT/kernel_stats.txt"
 exit $rc

@@ -21,5 +21,19 @@ def main(path, by_grid=False):
               f"{100.0 * tot / total:>6.2f} {vg:>5} {sg:>5} {lds:>6} {wg:>5}")
 
 
+def tail(path, spec):
+    """--tail SUBSTRING:N  average duration of the LAST N dispatches of the kernels whose name contains SUBSTRING
+    (bench.py's timed region is the end of a --no-extras run: its HIP-event figure roofline.avg_launch_us must agree)"""
+    sub, n = spec.rsplit(":", 1)
+    c = sqlite3.connect(path)
+    rows = c.execute("select duration from kernels where name like ? order by start desc limit ?", (f"%{sub}%", int(n))).fetchall()
+    if rows:
+        d = [r[0] for r in rows]
+        print(f"# last {len(d)} dispatches of *{sub}*: avg {sum(d) / len(d) / 1e3:.2f} us, min {min(d) / 1e3:.2f}, max {max(d) / 1e3:.2f}")
+
+
 if __name__ == "__main__":
     main(sys.argv[1], by_grid="--by-grid" in sys.argv[2:])
+    for i, a in enumerate(sys.argv):
+        if a == "--tail":
+            tail(sys.argv[1], sys.argv[i + 1])
