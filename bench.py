@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
     ap.add_argument("--traverse-waves", type=int, default=0, help="persistent wavefronts of a full-size traversal launch (0 = tuned default)")
     ap.add_argument("--ray-sort", type=int, default=0, help="1: direction-octant ray sorting of the pick-up order (config.ray_sort)")
+    ap.add_argument("--trace-variant", type=int, default=-1, help="closest-hit kernel (-1 = the library's default; 3 four-wide, 5 eight-wide tree)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
     ap.add_argument("--gather", choices=("rccl", "ipc"), default="rccl",
@@ -192,6 +193,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         # the smaller launches of a rank among 4 or 8
         pt.set_param("traverse_waves", args.traverse_waves or (5120 if world <= 2 else 2560))
         pt.set_param("ray_sort", args.ray_sort)
+        if args.trace_variant >= 0:
+            pt.set_trace_variant(args.trace_variant)
         pt.create_buffers((W, H), flat)
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
         if world > 1:

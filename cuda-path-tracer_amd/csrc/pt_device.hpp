@@ -58,6 +58,17 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //         Why it suffices for exactness: boxes nest exactly (parent = componentwise min/max of children) and
 //         IEEE subtraction/division are monotonic, so whenever a node passes the reference's box test all its
 //         ancestors pass too; a triangle is reachable in the reference iff its parent's box passes.
+//   bvh8: the same tree collapsed to EIGHT children per node, 80 bytes (20 dwords, five 16-byte loads) per node,
+//         breadth-first (pt_wide8.cpp): dwords 0-2 grid origin xyz; dword 3 = exponent bytes of the three power-of-two
+//         grid steps | imask << 24; dword 4 = child_base, dword 5 = tri_base, dword 6 = lmask; dwords 7-12 lower planes
+//         (lo_x[8] lo_y[8] lo_z[8], child slot s in byte s), dwords 13-18 upper planes; dword 19 unused.  Slot s holds an
+//         inner node iff imask bit s (node index child_base + popcount(imask below s)), a triangle iff lmask bit s
+//         (record tri_base + popcount(lmask below s)); an unused slot has an inside-out box.  Slots stand for octants
+//         of the node: a ray visits them in ascending (s XOR its direction-sign bits).
+//   tris8: per MESH OBJECT, world-space triangle records in bvh8's record order, three float4 each:
+//           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(depth-first rank), -, -}   (the normal is recomputed for the winner)
+//   leaf_parent8: leaf_parent in that record order.
+constexpr int kNode8Dwords = 20;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
 
@@ -74,6 +85,12 @@ struct DScene {
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
   const float4* leaf_parent;       // 2 float4 per triangle
   const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
+  const uint4* bvh8;               // the eight-wide nodes in 80 bytes (Wide8Accel::nodes), 5 x uint4 per node
+  const float4* tris8;             // 3 float4 per instance triangle, bvh8's record order
+  const float4* leaf_parent8;      // 2 float4 per triangle record
+  const uint32_t* object_tri_base8; // per object: first record of its instance in `tris8`
+  const uint32_t* record_of_rank8;  // depth-first rank -> triangle record (work splitting: another lane's candidate)
+  uint32_t bvh8_depth;
   uint32_t* slow_stack;            // global traversal stack of the launch's exact redo (redo_slow_rays), [kStackDepth][kWave]
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
@@ -207,7 +224,7 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                     uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi);
+                     uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi);
 // coherence sort of the pick-up order (never of the slots): octs = direction octant per slot (written by launch_shade
 // when given), order = per block of 4096 slots the slots grouped by octant; launch_traverse reads its rays through it
 void launch_sort_octant(hipStream_t s, const uint8_t* octs, uint32_t* order, uint32_t max_paths, int bounce,

@@ -1469,6 +1469,8 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   }
 }
 
+#include "pt_traverse8.inc"
+
 // A run of sphere objects that does not end the object list (the spheres in front of a mesh), continuing from /
 // handing on the closest hit in the hit record.  (The run that ENDS the list -- or is the whole list -- is part of
 // k_count_scan.)  (Taking the sphere runs into the traversal kernel instead was tried in round 2: inlined or as a
@@ -2162,9 +2164,19 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                     uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi)
+                     uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi)
 {
   const dim3 grid(waves), block(kWave);
+  if (variant == 5) {  // eight-wide tree (reads its rays in slot order: no pick-up order)
+    if (count_tests) {
+      if (first) hipLaunchKernelGGL((k_traverse8<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+      else hipLaunchKernelGGL((k_traverse8<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+    } else {
+      if (first) hipLaunchKernelGGL((k_traverse8<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+      else hipLaunchKernelGGL((k_traverse8<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
+    }
+    return;
+  }
   if (count_tests) {
     if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
     else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);

@@ -541,6 +541,33 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   }
   d.bvh4_root = w4.root_ref;
   d.dummy_ref = w4.dummy_ref;
+  // the eight-wide tree of k_traverse8, its triangle records per instance (own order) and their parent boxes
+  Wide8Accel w8;
+  if (int rc = build_wide8(nodes, node_count, w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
+  {
+    const uint32_t* q = nullptr;
+    if (int rc = upload(ctx, ctx->scene_allocs, &q, w8.nodes.data(), w8.nodes.size())) return rc;
+    d.bvh8 = reinterpret_cast<const uint4*>(q);
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent8, w8.leaf_parent.data(), w8.leaf_parent.size())) return rc;
+    const size_t records = w8.tri_of_record.size();
+    std::vector<uint32_t> base8(s->object_count, 0u);
+    size_t inst = 0;
+    for (uint32_t i = 0; i < s->object_count; ++i)
+      if (s->objects[i].type == 1u) base8[i] = (uint32_t)(inst++ * records);
+    std::vector<float4> tris8(inst * records * 3u);
+    for (uint32_t i = 0; i < s->object_count; ++i) {
+      if (s->objects[i].type != 1u || records == 0u) continue;
+      m4 m;
+      std::memcpy(&m, s->objects[i].m, sizeof m);
+      build_instance_triangles8(m, s->positions, s->indices, w8, tris8.data() + (size_t)base8[i] * 3u);
+    }
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.tris8, tris8.data(), tris8.size())) return rc;
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base8, base8.data(), base8.size())) return rc;
+    std::vector<uint32_t> record_of_rank(records, 0u);
+    for (size_t k = 0; k < records; ++k) record_of_rank[w8.rank_of_record[k]] = (uint32_t)k;
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.record_of_rank8, record_of_rank.data(), record_of_rank.size())) return rc;
+  }
+  d.bvh8_depth = w8.depth;
   d.refill_lanes = ctx->refill_lanes;
   d.split_idle = ctx->split_idle;
   d.static_eighths = ctx->static_eighths;
@@ -551,7 +578,13 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   // goes to this per-thread overflow area (the areas themselves belong to the frame slots, batch_begin)
   d.spill_cap = 0;
   d.lds_cap = ctx->lds_entries;
-  if (node_count) d.spill_cap = 3u * w4.depth + 2u > d.lds_cap ? 3u * w4.depth + 2u - d.lds_cap : 0u;
+  if (node_count) {
+    // four-wide walk: up to three refs per level; eight-wide walk: one group per level, 12 of them in LDS
+    const uint32_t need4 = 3u * w4.depth + 2u > d.lds_cap ? 3u * w4.depth + 2u - d.lds_cap : 0u;
+    const uint32_t lds8 = std::min<uint32_t>(d.lds_cap, 12u);
+    const uint32_t need8 = w8.depth + 2u > lds8 ? w8.depth + 2u - lds8 : 0u;
+    d.spill_cap = std::max(need4, need8);
+  }
   ctx->bvh4_nodes = w4.node_count;
   ctx->bvh4_depth = w4.depth;
   std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
@@ -777,7 +810,7 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  if (!ctx || (variant != 0 && variant != 1 && variant != 3)) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1 or 3)");
+  if (!ctx || (variant != 0 && variant != 1 && variant != 3 && variant != 5)) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
   if (variant == ctx->trace_variant) return PTC_OK;
   if (int rc = flush_pending(ctx)) return rc;
   ctx->trace_variant = variant;
@@ -970,9 +1003,10 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   };
   bool wrote = false;  // some launch of this bounce has written the hit records
   // ray sorting: the shade kernel of the previous bounce has tagged its surviving rays with their direction octant
+  const bool persistent = ctx->trace_variant >= 3;  // 3: four-wide tree, 5: eight-wide tree
   const bool sorted = ctx->ray_sort && ctx->trace_variant == 3 && bounce >= 1 && sl.order && !ctx->launches.empty();
   if (sorted) launch_sort_octant(sl.stream, sl.octs, sl.order, ctx->pix_count, bounce, sl.counters, sl.bi);
-  if (ctx->trace_variant == 3) {
+  if (persistent) {
     // closest hit = the object list walked by the launches of TraceLaunch
     for (size_t k = 0; k < ctx->launches.size(); ++k) {
       const auto& l = ctx->launches[k];
@@ -989,7 +1023,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       if (int rc = timed_begin(tl)) return rc;
       const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
       launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
-                      sl.slow_list, sorted ? sl.order : nullptr, sl.bi);
+                      sl.slow_list, sorted ? sl.order : nullptr, ctx->trace_variant, sl.bi);
       wrote = true;
       if (int rc = timed_end(tl)) return rc;
     }
@@ -1001,7 +1035,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     if (int rc = timed_end(tl)) return rc;
   }
   // the sphere run that ends the object list (variant 3 only) + the live counts; their scan
-  const bool tail = ctx->trace_variant == 3 && ctx->tail_begin < ctx->tail_end;
+  const bool tail = persistent && ctx->tail_begin < ctx->tail_end;
   launch_tail_count(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, sl.hits, ctx->pix_count,
                     bounce, sl.chunk_counts, sl.counters, sl.bi);
   launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
@@ -1036,7 +1070,7 @@ int batch_end(ptc_ctx* ctx)
 }
 
 // frames per batch ptc_trace may use right now (only the default traversal kernel reads DBatchInfo)
-int batch_limit(const ptc_ctx* ctx) { return ctx->staged && ctx->trace_variant == 3 ? ctx->batch : 1; }
+int batch_limit(const ptc_ctx* ctx) { return ctx->staged && ctx->trace_variant >= 3 ? ctx->batch : 1; }
 
 // enqueue the iterations ptc_trace has queued
 int flush_pending(ptc_ctx* ctx)
@@ -1540,7 +1574,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   // Path rays know two t_min values (1e-4, and 1e-5 after a dielectric: a flag bit) and start every bounce with
   // t_max = FLT_MAX; a caller's t_max enters as the "closest hit so far" the segments carry in the hit record.
   // Rays with another t_min take the one-wavefront-per-64-rays kernel with exact box decisions (variant 1).
-  bool path_like = ctx->trace_variant == 3;
+  bool path_like = ctx->trace_variant >= 3;
   for (uint32_t i = 0; i < n && path_like; ++i) {
     const float tmin = rays[8u * (size_t)i + 3u], tmax = rays[8u * (size_t)i + 7u];
     path_like = (tmin == 1e-4f || tmin == 1e-5f) && tmax >= 0.0f;
@@ -1607,7 +1641,8 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
         const auto& l = ctx->launches[k];
         if (l.pre_begin < l.pre_end)
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
-        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr, bi);
+        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr,
+                        ctx->trace_variant, bi);
       }
       launch_tail_count(ctx->stream, scene, ctx->tail_begin, ctx->tail_end, false, paths, hits, n, 0, chunk_counts, counters, bi);
       e = hipGetLastError();
@@ -1769,6 +1804,101 @@ int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, u
       if (p0.x != p.aabb_min[0] || p0.y != p.aabb_min[1] || p0.z != p.aabb_min[2] || p1.x != p.aabb_max[0] ||
           p1.y != p.aabb_max[1] || p1.z != p.aabb_max[2])
         ++bad;
+    }
+  }
+  // ---- the eight-wide tree of k_traverse8 (pt_wide8.cpp): the same obligations ----
+  {
+    Wide8Accel w8;
+    if (int rc = build_wide8(nodes, node_count, w8)) return rc;
+    const uint32_t n8 = w8.node_count, records = (uint32_t)w8.tri_of_record.size();
+    if (records != triangles || w8.rank_of_record.size() != records || w8.leaf_parent.size() != 2u * (size_t)records) ++bad;
+    std::vector<uint32_t> seen_rank(triangles, 0u), seen_record(records, 0u), seen_node(n8, 0u);
+    for (uint32_t k = 0; k < records && k < w8.rank_of_record.size(); ++k) {
+      const uint32_t r = w8.rank_of_record[k];
+      if (r >= triangles) {
+        ++bad;
+        continue;
+      }
+      ++seen_rank[r];
+      const uint32_t leaf = leaf_of_rank[r];
+      if (w8.tri_of_record[k] != nodes[leaf].first_child_or_primitive / 3u) ++bad;  // the record is that triangle
+      if (parent[leaf] != 0xffffffffu) {
+        const float4 p0 = w8.leaf_parent[2u * (size_t)k], p1 = w8.leaf_parent[2u * (size_t)k + 1u];
+        const ptc_bvh_node& p = nodes[parent[leaf]];
+        if (p0.x != p.aabb_min[0] || p0.y != p.aabb_min[1] || p0.z != p.aabb_min[2] || p1.x != p.aabb_max[0] ||
+            p1.y != p.aabb_max[1] || p1.z != p.aabb_max[2])
+          ++bad;
+      }
+    }
+    for (uint32_t r = 0; r < triangles; ++r)
+      if (seen_rank[r] != 1u) ++bad;
+    // rank range of every eight-wide node (children have larger indices: breadth-first)
+    std::vector<uint32_t> lo8(n8, 0xffffffffu), hi8(n8, 0u), cnt8(n8, 0u);
+    auto popc_below = [](uint32_t mask, int s) { return (uint32_t)__builtin_popcount(mask & ((1u << s) - 1u)); };
+    for (uint32_t n = n8; n-- > 0u;) {
+      const uint32_t* q = &w8.nodes[(size_t)n * kNode8Dwords];
+      const uint32_t imask = q[3] >> 24, lmask = q[6] & 0xffu;
+      if ((imask & lmask) != 0u || (imask | lmask) == 0u) ++bad;
+      for (int sl = 0; sl < 8; ++sl) {
+        if (lmask >> sl & 1u) {
+          const uint32_t k = q[5] + popc_below(lmask, sl);
+          if (k >= records) return PTC_ERR_BVH;
+          ++seen_record[k];
+          lo8[n] = std::min(lo8[n], w8.rank_of_record[k]);
+          hi8[n] = std::max(hi8[n], w8.rank_of_record[k]);
+          cnt8[n] += 1u;
+        } else if (imask >> sl & 1u) {
+          const uint32_t c = q[4] + popc_below(imask, sl);
+          if (c <= n || c >= n8) return PTC_ERR_BVH;
+          ++seen_node[c];
+          lo8[n] = std::min(lo8[n], lo8[c]);
+          hi8[n] = std::max(hi8[n], hi8[c]);
+          cnt8[n] += cnt8[c];
+        }
+      }
+    }
+    for (uint32_t k = 0; k < records; ++k)
+      if (seen_record[k] != 1u) ++bad;
+    for (uint32_t n = 1; n < n8; ++n)
+      if (seen_node[n] != 1u) ++bad;
+    if (n8 == 0u || cnt8[0] != triangles) ++bad;
+    // every quantised child box contains the exact box of the reference node the child stands for
+    for (uint32_t n = 0; n < n8; ++n) {
+      const uint32_t* q = &w8.nodes[(size_t)n * kNode8Dwords];
+      const uint32_t imask = q[3] >> 24, lmask = q[6] & 0xffu;
+      float origin[3];
+      std::memcpy(origin, q, 12);
+      for (int sl = 0; sl < 8; ++sl) {
+        const uint32_t w = (uint32_t)sl >> 2, sh = 8u * ((uint32_t)sl & 3u);
+        if (!((imask | lmask) >> sl & 1u)) {  // unused slot: inside-out on every axis
+          for (int ax = 0; ax < 3; ++ax)
+            if (((q[7 + 2 * ax + w] >> sh) & 0xffu) != 255u || ((q[13 + 2 * ax + w] >> sh) & 0xffu) != 0u) ++bad;
+          continue;
+        }
+        const ptc_bvh_node* x = nullptr;
+        if (lmask >> sl & 1u) {
+          x = &nodes[leaf_of_rank[w8.rank_of_record[q[5] + popc_below(lmask, sl)]]];
+        } else {
+          const uint32_t c = q[4] + popc_below(imask, sl);
+          if (hi8[c] - lo8[c] + 1u != cnt8[c]) {  // the child's leaves are one run of the depth-first order
+            ++bad;
+            continue;
+          }
+          const auto it = node_of_range.find(((uint64_t)lo8[c] << 32) | hi8[c]);
+          if (it == node_of_range.end()) {
+            ++bad;
+            continue;
+          }
+          x = &nodes[it->second];
+        }
+        for (int ax = 0; ax < 3; ++ax) {
+          const double step = std::ldexp(1.0, (int)((q[3] >> (8 * ax)) & 0xffu) - 127);
+          const double lo = (double)origin[ax] + (double)((q[7 + 2 * ax + w] >> sh) & 0xffu) * step;
+          const double hi = (double)origin[ax] + (double)((q[13 + 2 * ax + w] >> sh) & 0xffu) * step;
+          if (lo > (double)x->aabb_min[ax] || hi < (double)x->aabb_max[ax]) ++bad;
+        }
+        ++boxes;
+      }
     }
   }
   if (checked_boxes) *checked_boxes = boxes;

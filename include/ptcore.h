@@ -197,6 +197,10 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
  *                 winning triangle re-checked against its parent's box with the reference's arithmetic
  *                 (sufficient: see DESIGN.md "nesting"); objects walked as sphere / mesh segments; the only
  *                 variant that traces several iterations per launch ("batch_frames")
+ *   5           = the same persistent scheme over the tree collapsed to EIGHT children per 80-byte node (children
+ *                 in octant slots, visited in the order of the ray's direction signs, one (group, hit mask) stack
+ *                 entry per node).  26 % fewer node visits per ray but 45 % more box tests: measured 14 % slower
+ *                 than 3 on the benchmark scene; kept as a cross-check and for measurements
  *   1           = culled near-first traversal with exact box decisions, one wavefront per 64 fixed paths (the
  *                 walk the default uses for the few rays it sets aside)
  *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no

@@ -112,7 +112,7 @@ static bool tri_hit(const Ray& r, uint32_t t, float tmax, float& tout)
 struct Stats { double nodes = 0, boxes = 0, tris = 0, iters = 0; uint32_t max_nodes = 0; };
 
 // order: 0 = children sorted by entry distance; 1 = by the ray's direction octant (centroid projected on sign(d));
-//        2 = nearest child first, the rest in slot order
+//        2 = nearest child first, the rest in slot order; 3 = as stored
 static void walk(const Ray& r, int order, Stats& st)
 {
   float inv[3], best_t = r.tmax;
@@ -155,7 +155,9 @@ static void walk(const Ray& r, int order, Stats& st)
         ref[nh++] = w.kid[c];
       }
     }
-    if (order == 2) {
+    if (order == 3) {
+      // children as stored (no ordering at all)
+    } else if (order == 2) {
       int m = 0;
       for (int c = 1; c < nh; ++c)
         if (key[c] < key[m]) m = c;
@@ -182,10 +184,10 @@ int main(int argc, char** argv)
   if (fread(rays.data(), sizeof(Ray), rays.size(), f) != rays.size()) return 1;
   if (fread(per_bounce, 4, 8, f) != 8) return 1;
   fclose(f);
-  const char* names[3] = {"sorted by entry distance", "octant order (centroids)", "nearest first, rest unsorted"};
+  const char* names[4] = {"sorted by entry distance", "octant order (centroids)", "nearest first, rest unsorted", "as stored (no order)"};
   for (int k : {2, 4, 8}) {
     collapse(k);
-    for (int order = 0; order < 3; ++order) {
+    for (int order = 0; order < 4; ++order) {
       size_t at = 0;
       Stats all;
       printf("k=%d  %-30s  wide nodes %zu\n", k, names[order], wnodes.size());
