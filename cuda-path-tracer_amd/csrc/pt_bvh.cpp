@@ -9,6 +9,7 @@
 // because every decision is a function of the SET of triangles in a range.
 // Where the reference leaves the order of equal centroids to std::nth_element, ties go to the lower
 // triangle index.
+#include "pt_bvh_rules.hpp"
 #include "pt_host.hpp"
 
 #include <algorithm>
@@ -19,25 +20,8 @@
 #include <vector>
 
 namespace pt {
+using namespace bvh_rules;
 namespace {
-
-struct Box {
-  f3 lo, hi;
-};
-inline Box empty_box() { return Box{mk3(FLT_MAX, FLT_MAX, FLT_MAX), mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX)}; }
-inline Box grow(Box b, f3 p) { return Box{min3(b.lo, p), max3(b.hi, p)}; }
-inline Box merge(Box a, Box b) { return Box{min3(a.lo, b.lo), max3(a.hi, b.hi)}; }
-inline float area(const Box& b)
-{
-  const f3 d = b.hi - b.lo;
-  return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
-}
-inline int widest_axis(const Box& b)
-{
-  const f3 e = b.hi - b.lo;
-  return (e.x > e.y && e.x > e.z) ? 0 : (e.y > e.z) ? 1 : 2;
-}
-inline float comp(f3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 struct TmpNode {
   Box box;
@@ -65,21 +49,6 @@ struct Builder {
     return id;
   }
 
-  // normalised position of a centroid inside the centroid bounds along `axis` (AABB::offset, aabb.hpp:73-80)
-  static inline float offset_along(const Box& cb, f3 c, int axis)
-  {
-    const float lo = comp(cb.lo, axis), hi = comp(cb.hi, axis);
-    float o = comp(c, axis) - lo;
-    if (hi > lo) o /= hi - lo;
-    return o;
-  }
-  static inline int bucket_of(const Box& cb, f3 c, int axis)
-  {
-    int b = (int)(12.0f * offset_along(cb, c, axis));
-    if (b == 12) b = 11;
-    return b;
-  }
-
   // Builds the subtree over tris[0..n); returns its node id or -1.
   int32_t build(uint32_t* tris, uint32_t n, int spawn_depth)
   {
@@ -105,18 +74,17 @@ struct Builder {
     uint32_t mid;
     if (n <= 4) {
       std::sort(tris, tris + n, [&](uint32_t a, uint32_t b) {
-        const float ka = comp(tri_center[a], axis), kb = comp(tri_center[b], axis);
-        return ka < kb || (ka == kb && a < b);
+        return small_before(comp(tri_center[a], axis), a, comp(tri_center[b], axis), b);
       });
       mid = n / 2;
     } else {
-      int count[12] = {};
-      Box bounds[12];
+      int count[kBuckets] = {};
+      Box bounds[kBuckets];
       for (auto& b : bounds) b = empty_box();
       Box all = empty_box();
       for (uint32_t i = 0; i < n; ++i) {
         const int b = bucket_of(cb, tri_center[tris[i]], axis);
-        if (b < 0 || b > 11) {
+        if (b < 0 || b >= kBuckets) {
           error = PTC_ERR_BVH;
           return -1;
         }
@@ -124,26 +92,7 @@ struct Builder {
         bounds[b] = merge(bounds[b], tri_box[tris[i]]);
         all = merge(all, tri_box[tris[i]]);
       }
-      const float all_area = area(all);
-      int best = 0;
-      float best_cost = 0.0f;
-      for (int s = 0; s < 11; ++s) {
-        Box b0 = empty_box(), b1 = empty_box();
-        int c0 = 0, c1 = 0;
-        for (int j = 0; j <= s; ++j) {
-          b0 = merge(b0, bounds[j]);
-          c0 += count[j];
-        }
-        for (int j = s + 1; j < 12; ++j) {
-          b1 = merge(b1, bounds[j]);
-          c1 += count[j];
-        }
-        const float cost = .125f + ((float)c0 * area(b0) + (float)c1 * area(b1)) / all_area;
-        if (s == 0 || cost < best_cost) {
-          best_cost = cost;
-          best = s;
-        }
-      }
+      const int best = sah_best_split(count, bounds, all);
       uint32_t* split = std::partition(tris, tris + n, [&](uint32_t t) { return bucket_of(cb, tri_center[t], axis) <= best; });
       mid = (uint32_t)(split - tris);
       if (mid == 0 || mid == n) {  // reference: panic("Shouldn't happen!"), bvh.cpp:84-85
@@ -180,13 +129,11 @@ int build_bvh(const float* positions, uint32_t vertex_count, const uint32_t* ind
   std::vector<f3> tri_center(T);
   std::vector<uint32_t> tris(T);
   for (uint32_t t = 0; t < T; ++t) {
-    Box b = empty_box();
-    for (int k = 0; k < 3; ++k) {
-      const float* p = positions + 3u * (size_t)indices[3u * t + k];
-      b = grow(b, mk3(p[0], p[1], p[2]));
-    }
-    tri_box[t] = b;
-    tri_center[t] = (b.lo + b.hi) / 2.0f;
+    const float* p0 = positions + 3u * (size_t)indices[3u * t];
+    const float* p1 = positions + 3u * (size_t)indices[3u * t + 1u];
+    const float* p2 = positions + 3u * (size_t)indices[3u * t + 2u];
+    tri_box[t] = triangle_box(mk3(p0[0], p0[1], p0[2]), mk3(p1[0], p1[1], p1[2]), mk3(p2[0], p2[1], p2[2]));
+    tri_center[t] = box_center(tri_box[t]);
     tris[t] = t;
   }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/ptcore.h"
 #include "pt_math.hpp"
 
 namespace pt {
@@ -203,6 +204,12 @@ struct DDenoise {
   float c_phi, n_phi, p_phi;
   int variant;  // 0: taps staged in LDS per sub-lattice (k_denoise_lds, default); 1: taps through L1 / L2 (k_denoise)
 };
+
+// The reference BVH built on the device (pt_bvh_gpu.hip): the same tree as build_bvh (pt_bvh.cpp), node for node.
+// d_packed: 2 * (2T-1) float4 ({min, first}, {max, count}: DScene::bvh); d_nodes (may be null): the same nodes in the
+// reference's 32-byte layout.  Synchronises the stream (one readback per tree level).
+int build_bvh_device(hipStream_t stream, const float* d_positions, const uint32_t* d_indices, uint32_t index_count,
+                     float4* d_packed, ptc_bvh_node* d_nodes, uint32_t* node_count, uint32_t* max_depth);
 
 // ---- launch interface (implemented in pt_kernels.hip) ----
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -59,6 +60,7 @@ struct ptc_ctx {
   DScene scene{};
   bool has_scene = false;
   uint32_t bvh_nodes = 0, bvh_depth = 0, triangles = 0, bvh4_nodes = 0, bvh4_depth = 0;
+  ptc_upload_times upload_times{};
 
   // frame
   uint32_t width = 0, height = 0;
@@ -162,6 +164,7 @@ struct ptc_ctx {
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
+  bool bvh_on_device = true;  // "bvh_build_on_device": the reference BVH of ptc_upload_scene from pt_bvh_gpu.hip
   uint32_t split_idle = 8;    // "split_idle"
   uint32_t min_waves = 1024;  // "min_waves": fewest persistent wavefronts of a traversal launch
   // live paths entering each bounce of one recent frame (what a frame of this scene / camera looks like): the host
@@ -455,14 +458,60 @@ int ptc_set_stream(ptc_ctx* ctx, void* hip_stream)
   return PTC_OK;
 }
 
+namespace {
+// The reference BVH of a mesh built on the device.  nodes_host gets the 2T-1 nodes in the reference's layout;
+// *packed_out (when asked for) keeps the device copy in DScene::bvh's layout, owned by the caller.
+int bvh_on_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                  ptc_bvh_node* nodes_host, uint32_t* max_depth, float4** packed_out)
+{
+  const uint32_t T = index_count / 3u;
+  if (T == 0u) return fail(ctx, PTC_ERR_BVH, "empty mesh");
+  for (uint32_t i = 0; i < T * 3u; ++i)
+    if (indices[i] >= vertex_count) return fail(ctx, PTC_ERR_INVALID, "vertex index out of range");
+  std::vector<void*> pool;
+  const float* d_pos = nullptr;
+  const uint32_t* d_idx = nullptr;
+  float4* d_packed = nullptr;
+  ptc_bvh_node* d_nodes = nullptr;
+  const size_t count = 2u * (size_t)T - 1u;
+  int rc = upload(ctx, pool, &d_pos, positions, (size_t)vertex_count * 3u);
+  if (!rc) rc = upload(ctx, pool, &d_idx, indices, (size_t)T * 3u);
+  if (!rc) rc = dev_alloc(ctx, pool, &d_packed, 2u * count);
+  if (!rc) rc = dev_alloc(ctx, pool, &d_nodes, count);
+  uint32_t built = 0u;
+  if (!rc) {
+    rc = build_bvh_device(ctx->stream, d_pos, d_idx, T * 3u, d_packed, d_nodes, &built, max_depth);
+    if (rc) fail(ctx, rc, rc == PTC_ERR_BVH ? "BVH build failed (empty SAH side: coincident centroids?)" : "device BVH build failed");
+  }
+  if (!rc && hipMemcpy(nodes_host, d_nodes, count * sizeof(ptc_bvh_node), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = fail(ctx, PTC_ERR_HIP, "device BVH download failed");
+  for (void* p : pool)
+    if (p != d_packed || rc || !packed_out) (void)hipFree(p);
+  if (!rc && packed_out) *packed_out = d_packed;
+  return rc ? rc : (int)built;
+}
+}  // namespace
+
 int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
 {
   if (!ctx || !s) return PTC_ERR_INVALID;
   if (int rc = bind_device(ctx)) return rc;
   if (int rc = validate_scene(ctx, s)) return rc;
 
+  ptc_upload_times times{};
+  auto t_start = std::chrono::steady_clock::now(), t_lap = t_start;
+  auto lap = [&](float& into) {
+    const auto now = std::chrono::steady_clock::now();
+    into += std::chrono::duration<float, std::milli>(now - t_lap).count();
+    t_lap = now;
+  };
   // bottom-level BVH (scene_description.cpp:99-101), unless the caller brought one
   std::vector<ptc_bvh_node> built;
+  float4* dev_packed = nullptr;  // the device builder's output, already in DScene::bvh's layout
+  struct Guard {                 // (not leaked by the error returns below)
+    float4*& p;
+    ~Guard() { if (p) (void)hipFree(p); }
+  } guard{dev_packed};
   const ptc_bvh_node* nodes = s->bvh;
   uint32_t node_count = s->bvh ? s->bvh_node_count : 0u;
   uint32_t depth = 0;
@@ -471,14 +520,23 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     node_count = 0u;  // the reference panics on an empty mesh (bvh.cpp:200); here it is a scene without mesh
   } else if (!nodes) {
     built.resize((size_t)s->index_count / 3u * 2u);
-    const int rc = build_bvh(s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth);
-    if (rc < 0) return fail(ctx, rc, "BVH build failed (empty SAH side: coincident centroids?)");
+    int rc;
+    if (ctx->bvh_on_device) {
+      rc = bvh_on_device(ctx, s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth, &dev_packed);
+      if (rc < 0) return rc;
+      times.bvh_on_device = 1u;
+    } else {
+      rc = build_bvh(s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth);
+      if (rc < 0) return fail(ctx, rc, "BVH build failed (empty SAH side: coincident centroids?)");
+    }
     node_count = (uint32_t)rc;
     nodes = built.data();
   } else {
     if (int rc = validate_bvh(ctx, nodes, node_count, s->index_count)) return rc;
     depth = bvh_depth_of(nodes, node_count);
   }
+  lap(times.bvh_build_ms);
+  if (s->bvh) times.bvh_build_ms = 0.0f;
   // depth-first traversal pushes two children per inner node popped: stack need = depth + 1
   if (node_count && depth + 2u > (uint32_t)kStackDepth)
     return fail(ctx, PTC_ERR_STACK, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack");
@@ -499,8 +557,8 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (int rc = upload(ctx, ctx->scene_allocs, &d.positions, s->positions, (size_t)s->vertex_count * 3u)) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.indices, s->indices, s->index_count)) return rc;
   // node -> two float4: {min.xyz, first}, {max.xyz, count}
-  std::vector<float4> packed((size_t)node_count * 2u);
-  for (uint32_t i = 0; i < node_count; ++i) {
+  std::vector<float4> packed(dev_packed ? 0u : (size_t)node_count * 2u);
+  for (uint32_t i = 0; i < node_count && !dev_packed; ++i) {
     const ptc_bvh_node& n = nodes[i];
     float fbits, cbits;
     std::memcpy(&fbits, &n.first_child_or_primitive, 4);
@@ -508,12 +566,21 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     packed[2u * i] = make_float4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], fbits);
     packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
   }
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) return rc;
+  if (dev_packed) {
+    ctx->scene_allocs.push_back(dev_packed);
+    d.bvh = dev_packed;
+    dev_packed = nullptr;
+  } else if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) {
+    return rc;
+  }
+  lap(times.copy_ms);
 
   // layout for the fast traversal: wide inner records + per-instance world-space triangles
   WideAccel wa;
   if (int rc = build_wide(nodes, node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
+  lap(times.layout_ms);
   if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
+  lap(times.copy_ms);
   // per instance: the mesh's triangles + one all-zero record, the dummy triangle of the four-wide tree's unused
   // child slots (Wide4Accel::dummy_ref)
   const size_t inst_tris = wa.tri_order.size() + 1u;
@@ -529,10 +596,13 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     std::memcpy(&m, s->objects[i].m, sizeof m);
     build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * 3u);
   }
+  lap(times.triangles_ms);
   if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
+  lap(times.copy_ms);
   Wide4Accel w4;
   if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
+  lap(times.layout_ms);
   if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
   {
     const uint32_t* q = nullptr;
@@ -541,9 +611,11 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   }
   d.bvh4_root = w4.root_ref;
   d.dummy_ref = w4.dummy_ref;
+  lap(times.copy_ms);
   // the eight-wide tree of k_traverse8, its triangle records per instance (own order) and their parent boxes
   Wide8Accel w8;
   if (int rc = build_wide8(nodes, node_count, w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
+  lap(times.layout_ms);
   {
     const uint32_t* q = nullptr;
     if (int rc = upload(ctx, ctx->scene_allocs, &q, w8.nodes.data(), w8.nodes.size())) return rc;
@@ -561,11 +633,13 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
       std::memcpy(&m, s->objects[i].m, sizeof m);
       build_instance_triangles8(m, s->positions, s->indices, w8, tris8.data() + (size_t)base8[i] * 3u);
     }
+    lap(times.triangles_ms);
     if (int rc = upload(ctx, ctx->scene_allocs, &d.tris8, tris8.data(), tris8.size())) return rc;
     if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base8, base8.data(), base8.size())) return rc;
     std::vector<uint32_t> record_of_rank(records, 0u);
     for (size_t k = 0; k < records; ++k) record_of_rank[w8.rank_of_record[k]] = (uint32_t)k;
     if (int rc = upload(ctx, ctx->scene_allocs, &d.record_of_rank8, record_of_rank.data(), record_of_rank.size())) return rc;
+    lap(times.copy_ms);
   }
   d.bvh8_depth = w8.depth;
   d.refill_lanes = ctx->refill_lanes;
@@ -617,6 +691,25 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   ctx->bvh_nodes = node_count;
   ctx->bvh_depth = depth;
   ctx->triangles = s->index_count / 3u;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, PTC_ERR_HIP, "scene upload failed");
+  lap(times.copy_ms);
+  times.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  ctx->upload_times = times;
+  return PTC_OK;
+}
+
+int ptc_build_bvh_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_count, const uint32_t* indices,
+                         uint32_t index_count, ptc_bvh_node* nodes, uint32_t* max_depth)
+{
+  if (!ctx || !positions || !indices || !nodes || index_count % 3u != 0u) return fail(ctx, PTC_ERR_INVALID, "bad arguments");
+  if (int rc = bind_device(ctx)) return rc;
+  return bvh_on_device(ctx, positions, vertex_count, indices, index_count, nodes, max_depth, nullptr);
+}
+
+int ptc_get_upload_times(const ptc_ctx* ctx, ptc_upload_times* out)
+{
+  if (!ctx || !out) return PTC_ERR_INVALID;
+  *out = ctx->upload_times;
   return PTC_OK;
 }
 
@@ -842,6 +935,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (std::strcmp(name, "debug_force_slow") == 0) {
     ctx->scene.force_slow = (uint32_t)value;  // 1: every ray at fetch time, 2: every winner at verification time
     ctx->force_slow = value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "bvh_build_on_device") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "bvh_build_on_device must be 0 or 1");
+    ctx->bvh_on_device = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "static_eighths") == 0) {

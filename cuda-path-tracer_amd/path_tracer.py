@@ -224,6 +224,26 @@ class PathTracer:
                 "bvh_node_count": int(s.bvh_node_count), "bvh_max_depth": int(s.bvh_max_depth),
                 "triangle_count": int(s.triangle_count), "stack_capacity": int(s.stack_capacity)}
 
+    def build_bvh(self, mesh):
+        """bvh_from_mesh (accelerators/bvh.cpp:211-253) on this context's GPU (ptc_build_bvh_device): the nodes the
+        host builder (scene_description.bvh_from_mesh) returns.  -> (nodes structured array, max_depth)"""
+        from .scene_description import BVH_NODE_DTYPE
+        t = mesh.triangle_count()
+        nodes = np.zeros(max(2 * t - 1, 1), dtype=BVH_NODE_DTYPE)
+        depth = C.c_uint32(0)
+        rc = self._lib.ptc_build_bvh_device(self._ctx, mesh.positions.ctypes.data_as(C.POINTER(C.c_float)), len(mesh.positions),
+                                            mesh.indices.ctypes.data_as(C.POINTER(C.c_uint32)), len(mesh.indices),
+                                            nodes.ctypes.data_as(C.POINTER(_capi.ptc_bvh_node)), C.byref(depth))
+        if rc < 0:
+            self._check(rc)
+        return nodes[:rc], depth.value
+
+    def upload_times(self):
+        """milliseconds of the last scene upload by stage (ptc_upload_times)"""
+        t = _capi.ptc_upload_times()
+        self._check(self._lib.ptc_get_upload_times(self._ctx, C.byref(t)))
+        return {k: (int(getattr(t, k)) if k == "bvh_on_device" else round(float(getattr(t, k)), 2)) for k, _ in t._fields_}
+
     def set_trace_variant(self, variant):
         self._check(self._lib.ptc_set_trace_variant(self._ctx, int(variant)))
 

@@ -216,6 +216,8 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      The library asks the HIP runtime for 24 hardware queues (GPU_MAX_HW_QUEUES, default 4:
  *                      streams on one queue serialise) when it is loaded before the runtime starts; an
  *                      application that initialises HIP first should export GPU_MAX_HW_QUEUES=24 itself
+ *   "bvh_build_on_device"  1 (default): a scene without BVH gets the reference BVH from the GPU builder
+ *                      (ptc_build_bvh_device); 0: from the threaded host builder.  Same nodes either way
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
@@ -329,10 +331,27 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out);                /* synchroni
 int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t, float* hit_normal,
                        uint32_t* hit_material, uint8_t* hit_side);
 
+/* Where the time of the last ptc_upload_scene went (milliseconds of host wall clock; the "Initialization" stage of
+ * the reference's Stopwatch, cli.cpp): */
+typedef struct ptc_upload_times {
+  float bvh_build_ms;   /* the reference BVH (0 when the caller brought one) */
+  float layout_ms;      /* collapsed / quantised traversal trees derived from it */
+  float triangles_ms;   /* per-instance world-space triangle records */
+  float copy_ms;        /* hipMalloc + host-to-device copies (includes packing the reference nodes) */
+  float total_ms;
+  uint32_t bvh_on_device; /* 1: the reference BVH was built by the GPU builder */
+} ptc_upload_times;
+int ptc_get_upload_times(const ptc_ctx* ctx, ptc_upload_times* out);
+
 /* bvh_from_mesh (accelerators/bvh.cpp:211-253), host-side, no GPU needed.  nodes must hold
  * index_count/3*2-1 entries.  Returns the node count (>0) or a negative ptc_status. */
 int ptc_build_bvh(const float* positions, uint32_t vertex_count, const uint32_t* indices,
                   uint32_t index_count, ptc_bvh_node* nodes, uint32_t* max_depth);
+/* The same tree built by the context's GPU (pt_bvh_gpu.hip: all nodes of a depth split at once; the decisions are
+ * the host builder's, from one source) -- node for node what ptc_build_bvh returns.  This is what ptc_upload_scene
+ * runs when the scene brings no BVH (param "bvh_build_on_device", default 1; 0 = the host builder). */
+int ptc_build_bvh_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_count, const uint32_t* indices,
+                         uint32_t index_count, ptc_bvh_node* nodes, uint32_t* max_depth);
 
 /* Per-object part of SceneDescription::build_scene (scene_description.cpp:17-52): fills inv_m
  * (glm::inverse) and the world AABB.  sphere / mesh_aabb6 (min xyz, max xyz) as the type needs. */
