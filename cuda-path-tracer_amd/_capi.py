@@ -92,7 +92,7 @@ class ptc_profile(C.Structure):
 
 class ptc_upload_times(C.Structure):
     _fields_ = [("bvh_build_ms", C.c_float), ("layout_ms", C.c_float), ("triangles_ms", C.c_float), ("copy_ms", C.c_float),
-                ("total_ms", C.c_float), ("bvh_on_device", C.c_uint32)]
+                ("total_ms", C.c_float), ("bvh_on_device", C.c_uint32), ("layout_on_device", C.c_uint32)]
 
 
 # every symbol include/ptcore.h declares: name -> (restype, argtypes)
@@ -140,6 +140,7 @@ SIGNATURES = {
     "ptc_intersect_rays": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
     "ptc_get_upload_times": (C.c_int, [_P, C.POINTER(ptc_upload_times)]),
+    "ptc_download_layout": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "ptc_build_bvh_device": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
                                        C.POINTER(ptc_bvh_node), C.POINTER(C.c_uint32)]),
     "ptc_build_bvh": (C.c_int, [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,

@@ -29,6 +29,7 @@
 #include "../../include/ptcore.h"
 #include "pt_bvh_rules.hpp"
 #include "pt_device.hpp"
+#include "pt_layout_rules.hpp"
 
 namespace pt {
 using namespace bvh_rules;
@@ -405,7 +406,8 @@ struct Pool {
 }  // namespace
 
 int build_bvh_device(hipStream_t stream, const float* d_positions, const uint32_t* d_indices, uint32_t index_count,
-                     float4* d_packed, ptc_bvh_node* d_nodes, uint32_t* node_count, uint32_t* max_depth)
+                     float4* d_packed, ptc_bvh_node* d_nodes, uint32_t* node_count, uint32_t* max_depth,
+                     std::vector<uint32_t>* level_base)
 {
   const uint32_t T = index_count / 3u;
   if (T == 0u) return PTC_ERR_BVH;
@@ -444,6 +446,7 @@ int build_bvh_device(hipStream_t stream, const float* d_positions, const uint32_
   int rc = PTC_OK;
   uint32_t base = 0u, m = 1u, depth = 0u;
   int src = 0;
+  if (level_base) level_base->assign(1, 0u);
   for (;;) {
     // rank of every inner node among the inner nodes of its level, and their number
     scan_u32(stream, lv.inner + base, lv.rank + base, m, scan_tmp, lv.status + 1);
@@ -458,6 +461,7 @@ int build_bvh_device(hipStream_t stream, const float* d_positions, const uint32_
     }
     const uint32_t inner = host_status[1];
     const uint32_t next_base = base + m;
+    if (level_base) level_base->push_back(next_base);
     if ((size_t)next_base + 2u * (size_t)inner > N) {  // cannot happen: a binary tree over T leaves has 2T-1 nodes
       rc = PTC_ERR_BVH;
       break;
@@ -499,6 +503,296 @@ int build_bvh_device(hipStream_t stream, const float* d_positions, const uint32_
   if (node_count) *node_count = base;
   if (max_depth) *max_depth = depth;
   return PTC_OK;
+}
+
+
+// =====================================================================================================================
+// Part 2: the traversal layouts derived from the reference tree, on the device (what pt_scene_host.cpp does on the
+// host; the decisions -- collapse costs, choice of children, node encoding -- come from pt_layout_rules.hpp, so the
+// bytes are the same).  The tree is swept level by level: up for the collapse costs and leaf counts, down for the
+// depth-first leaf ranks and for which nodes become four-wide nodes, up for the number of those below every node,
+// down for their depth-first preorder indices; then one pass writes all records.
+// =====================================================================================================================
+namespace {
+
+struct DevTree {
+  const float4* bvh;
+  __host__ __device__ bool is_leaf(uint32_t x) const { return __builtin_bit_cast(uint32_t, bvh[2u * (size_t)x + 1u].w) != 0u; }
+  __host__ __device__ uint32_t first(uint32_t x) const { return __builtin_bit_cast(uint32_t, bvh[2u * (size_t)x].w); }
+};
+
+struct LayoutWork {
+  DevTree tree;
+  uint32_t count;
+  uint32_t* parent;
+  uint32_t* leaves;      // triangles below the node
+  uint32_t* leaf_begin;  // depth-first rank of the node's first triangle
+  float* best;           // 4 per node (layout_rules::collapse_costs)
+  uint32_t* kept;        // 0, or 1 | children << 8: the node becomes a four-wide node
+  uint32_t* kids;        // 4 per node
+  uint32_t* wsub;        // four-wide nodes in the node's subtree
+  uint32_t* wbegin;      // depth-first preorder index of the first of them
+  uint32_t* wlevel;      // level of a four-wide node in the four-wide tree
+  uint32_t* inner;       // 1: inner node
+  uint32_t* inner_rank;  // rank among the inner nodes in array order (WideAccel's record index)
+  uint32_t* status;      // [0] deepest four-wide level + 1
+  // outputs
+  uint32_t* nodes_q;
+  float4* leaf_parent;
+  uint32_t* tri_order;
+  float4* wide;
+  uint32_t dummy_ref;
+};
+
+__device__ __forceinline__ float node_area(const float4* bvh, uint32_t x)
+{
+  const float4 a = bvh[2u * (size_t)x], b = bvh[2u * (size_t)x + 1u];
+  const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+  return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+
+__global__ __launch_bounds__(256) void k_lay_parent(LayoutWork w)
+{
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+  if (x >= w.count) return;
+  const bool leaf = w.tree.is_leaf(x);
+  w.inner[x] = leaf ? 0u : 1u;
+  if (x == 0u) w.parent[0] = 0xffffffffu;
+  if (!leaf) {
+    const uint32_t l = w.tree.first(x);
+    w.parent[l] = x;
+    w.parent[l + 1u] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lay_up_cost(LayoutWork w, uint32_t base, uint32_t m)
+{
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t x = base + k;
+  float* b = w.best + 4u * (size_t)x;
+  if (w.tree.is_leaf(x)) {
+    w.leaves[x] = 1u;
+    b[0] = b[1] = b[2] = b[3] = 0.0f;
+    return;
+  }
+  const uint32_t l = w.tree.first(x);
+  layout_rules::collapse_costs(node_area(w.tree.bvh, x), w.best + 4u * (size_t)l, w.best + 4u * (size_t)l + 4u, b);
+  w.leaves[x] = w.leaves[l] + w.leaves[l + 1u];
+}
+
+__global__ __launch_bounds__(256) void k_lay_down_keep(LayoutWork w, uint32_t base, uint32_t m)
+{
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t x = base + k;
+  if (w.tree.is_leaf(x)) {
+    if (x == 0u) w.leaf_begin[0] = 0u;
+    return;
+  }
+  if (x == 0u) {
+    w.leaf_begin[0] = 0u;
+    w.wlevel[0] = 0u;
+    w.kept[0] = 1u;
+  }
+  const uint32_t l = w.tree.first(x);
+  const uint32_t begin = w.leaf_begin[x];
+  w.leaf_begin[l] = begin;
+  w.leaf_begin[l + 1u] = begin + w.leaves[l];
+  if (w.kept[x] == 0u) return;
+  uint32_t kids[4];
+  const int nk = layout_rules::choose_children(w.tree, w.best, x, kids);
+  const uint32_t level = w.wlevel[x];
+  for (int c = 0; c < nk; ++c) {
+    w.kids[4u * (size_t)x + c] = kids[c];
+    if (!w.tree.is_leaf(kids[c])) {
+      w.kept[kids[c]] = 1u;
+      w.wlevel[kids[c]] = level + 1u;
+    }
+  }
+  w.kept[x] = 1u | ((uint32_t)nk << 8);
+  atomicMax(&w.status[0], level + 1u);
+}
+
+__global__ __launch_bounds__(256) void k_lay_up_wsub(LayoutWork w, uint32_t base, uint32_t m)
+{
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t x = base + k;
+  uint32_t n = w.kept[x] != 0u ? 1u : 0u;
+  if (!w.tree.is_leaf(x)) {
+    const uint32_t l = w.tree.first(x);
+    n += w.wsub[l] + w.wsub[l + 1u];
+  }
+  w.wsub[x] = n;
+}
+
+__global__ __launch_bounds__(256) void k_lay_down_wbegin(LayoutWork w, uint32_t base, uint32_t m)
+{
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t x = base + k;
+  if (x == 0u) w.wbegin[0] = 0u;
+  if (w.tree.is_leaf(x)) return;
+  const uint32_t l = w.tree.first(x);
+  const uint32_t first = w.wbegin[x] + (w.kept[x] != 0u ? 1u : 0u);
+  w.wbegin[l] = first;
+  w.wbegin[l + 1u] = first + w.wsub[l];
+}
+
+__global__ __launch_bounds__(128) void k_lay_emit(LayoutWork w)
+{
+  const uint32_t x = blockIdx.x * 128u + threadIdx.x;
+  if (x >= w.count) return;
+  const float4* bvh = w.tree.bvh;
+  if (w.tree.is_leaf(x)) {
+    const uint32_t rank = w.leaf_begin[x];
+    const uint32_t p = w.parent[x];
+    // a single-triangle mesh has no inner node at all: every box test of the reference is vacuous
+    const float big = 3.402823466e+38f;
+    float4 lo = make_float4(-big, -big, -big, 0.f), hi = make_float4(big, big, big, 0.f);
+    if (p != 0xffffffffu) {
+      const float4 a = bvh[2u * (size_t)p], b = bvh[2u * (size_t)p + 1u];
+      lo = make_float4(a.x, a.y, a.z, 0.f);
+      hi = make_float4(b.x, b.y, b.z, 0.f);
+    }
+    w.leaf_parent[2u * (size_t)rank] = lo;
+    w.leaf_parent[2u * (size_t)rank + 1u] = hi;
+    w.tri_order[rank] = w.tree.first(x) / 3u;
+    return;
+  }
+  auto ref2 = [&](uint32_t c) { return w.tree.is_leaf(c) ? (kLeafBit | w.leaf_begin[c]) : w.inner_rank[c]; };
+  {  // the two-child record of the exact near-first walk (WideAccel::wide)
+    const uint32_t l = w.tree.first(x);
+    const float4 la = bvh[2u * (size_t)l], lb = bvh[2u * (size_t)l + 1u];
+    const float4 ra = bvh[2u * (size_t)l + 2u], rb = bvh[2u * (size_t)l + 3u];
+    float4* rec = w.wide + 4u * (size_t)w.inner_rank[x];
+    rec[0] = make_float4(la.x, la.y, la.z, lb.x);
+    rec[1] = make_float4(lb.y, lb.z, ra.x, ra.y);
+    rec[2] = make_float4(ra.z, rb.x, rb.y, rb.z);
+    rec[3] = make_float4(__uint_as_float(ref2(l)), __uint_as_float(ref2(l + 1u)), 0.0f, 0.0f);
+  }
+  const uint32_t kept = w.kept[x];
+  if (kept == 0u) return;
+  const int nk = (int)(kept >> 8);
+  float lo[3][4], hi[3][4];
+  uint32_t refs[4];
+  for (int c = 0; c < 4; ++c) {
+    if (c < nk) {
+      const uint32_t kid = w.kids[4u * (size_t)x + c];
+      const float4 a = bvh[2u * (size_t)kid], b = bvh[2u * (size_t)kid + 1u];
+      lo[0][c] = a.x; lo[1][c] = a.y; lo[2][c] = a.z;
+      hi[0][c] = b.x; hi[1][c] = b.y; hi[2][c] = b.z;
+      refs[c] = w.tree.is_leaf(kid) ? (kLeafBit | w.leaf_begin[kid]) : w.wbegin[kid];
+    } else {
+      for (int a = 0; a < 3; ++a) lo[a][c] = hi[a][c] = 0.0f;
+      refs[c] = w.dummy_ref;
+    }
+  }
+  uint32_t q[16];
+  layout_rules::quantise_node(q, nk, lo, hi, refs);
+  uint4* out = reinterpret_cast<uint4*>(w.nodes_q) + 4u * (size_t)w.wbegin[x];
+  for (int j = 0; j < 4; ++j) out[j] = make_uint4(q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3]);
+}
+
+__global__ __launch_bounds__(256) void k_lay_instance_tris(m4 m, const float* positions, const uint32_t* indices,
+                                                           const uint32_t* tri_order, uint32_t T, float4* out)
+{
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= T) return;
+  const uint32_t* idx = indices + 3u * (size_t)tri_order[k];
+  const float* q0 = positions + 3u * (size_t)idx[0];
+  const float* q1 = positions + 3u * (size_t)idx[1];
+  const float* q2 = positions + 3u * (size_t)idx[2];
+  layout_rules::instance_triangle(m, mk3(q0[0], q0[1], q0[2]), mk3(q1[0], q1[1], q1[2]), mk3(q2[0], q2[1], q2[2]), out + 3u * (size_t)k);
+}
+
+}  // namespace
+
+int build_layouts_device(hipStream_t stream, const float4* d_bvh, uint32_t count, const std::vector<uint32_t>& level_base,
+                         DeviceLayouts* out)
+{
+  *out = DeviceLayouts{};
+  if (count == 0u) return PTC_OK;
+  if (level_base.size() < 2u || level_base.front() != 0u || level_base.back() != count) return PTC_ERR_INVALID;
+  const uint32_t T = (count + 1u) / 2u;
+  const size_t N = count;
+  Pool pool;
+  LayoutWork w{};
+  w.tree.bvh = d_bvh;
+  w.count = count;
+  w.parent = pool.get<uint32_t>(N);
+  w.leaves = pool.get<uint32_t>(N);
+  w.leaf_begin = pool.get<uint32_t>(N);
+  w.best = pool.get<float>(4u * N);
+  w.kept = pool.get<uint32_t>(N);
+  w.kids = pool.get<uint32_t>(4u * N);
+  w.wsub = pool.get<uint32_t>(N);
+  w.wbegin = pool.get<uint32_t>(N);
+  w.wlevel = pool.get<uint32_t>(N);
+  w.inner = pool.get<uint32_t>(N);
+  w.inner_rank = pool.get<uint32_t>(N);
+  w.status = pool.get<uint32_t>(4);
+  uint32_t* scan_tmp = pool.get<uint32_t>(2u * (N / 1024u + 2u) + 2u * (N / (1024u * 1024u) + 2u) + 16u);
+  // outputs: owned by the caller once returned
+  Pool outputs;
+  w.leaf_parent = outputs.get<float4>(2u * ((size_t)T + 1u));
+  w.tri_order = outputs.get<uint32_t>(T);
+  w.wide = outputs.get<float4>(4u * (size_t)std::max(T - 1u, 1u));
+  w.dummy_ref = kLeafBit | T;
+  if (pool.failed || outputs.failed) return PTC_ERR_OOM;
+  const size_t levels = level_base.size() - 1u;
+  auto grid = [](uint32_t m) { return dim3((m + 255u) / 256u); };
+  const dim3 b256(256);
+  bool ok = hipMemsetAsync(w.kept, 0, N * sizeof(uint32_t), stream) == hipSuccess &&
+            hipMemsetAsync(w.status, 0, 4 * sizeof(uint32_t), stream) == hipSuccess &&
+            hipMemsetAsync(w.leaf_parent + 2u * (size_t)T, 0, 2 * sizeof(float4), stream) == hipSuccess;
+  hipLaunchKernelGGL(k_lay_parent, grid(count), b256, 0, stream, w);
+  scan_u32(stream, w.inner, w.inner_rank, count, scan_tmp, w.status + 2);
+  for (size_t l = levels; l-- > 0u;)
+    hipLaunchKernelGGL(k_lay_up_cost, grid(level_base[l + 1] - level_base[l]), b256, 0, stream, w, level_base[l], level_base[l + 1] - level_base[l]);
+  for (size_t l = 0; l < levels; ++l)
+    hipLaunchKernelGGL(k_lay_down_keep, grid(level_base[l + 1] - level_base[l]), b256, 0, stream, w, level_base[l], level_base[l + 1] - level_base[l]);
+  for (size_t l = levels; l-- > 0u;)
+    hipLaunchKernelGGL(k_lay_up_wsub, grid(level_base[l + 1] - level_base[l]), b256, 0, stream, w, level_base[l], level_base[l + 1] - level_base[l]);
+  for (size_t l = 0; l < levels; ++l)
+    hipLaunchKernelGGL(k_lay_down_wbegin, grid(level_base[l + 1] - level_base[l]), b256, 0, stream, w, level_base[l], level_base[l + 1] - level_base[l]);
+  uint32_t host[4] = {0u, 0u, 0u, 0u};  // deepest level + 1 | . | . | four-wide nodes
+  float4 root[2];
+  ok = ok && hipMemcpyAsync(&host[0], w.status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+       hipMemcpyAsync(&host[3], w.wsub, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+       hipMemcpyAsync(root, d_bvh, 2 * sizeof(float4), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+       hipStreamSynchronize(stream) == hipSuccess;
+  if (!ok) return PTC_ERR_HIP;
+  const uint32_t wide4_nodes = host[3];
+  w.nodes_q = outputs.get<uint32_t>(16u * (size_t)std::max(wide4_nodes, 1u));
+  if (outputs.failed) return PTC_ERR_OOM;
+  hipLaunchKernelGGL(k_lay_emit, dim3((count + 127u) / 128u), dim3(128), 0, stream, w);
+  if (hipStreamSynchronize(stream) != hipSuccess) return PTC_ERR_HIP;
+  out->nodes_q = w.nodes_q;
+  out->leaf_parent = w.leaf_parent;
+  out->tri_order = w.tri_order;
+  out->wide = w.wide;
+  out->wide4_nodes = wide4_nodes;
+  out->wide4_depth = host[0];
+  out->triangles = T;
+  out->inner_nodes = T - 1u;
+  const bool root_is_leaf = __builtin_bit_cast(uint32_t, root[1].w) != 0u;
+  out->root_ref4 = root_is_leaf ? kLeafBit : 0u;
+  out->root_ref2 = root_is_leaf ? kLeafBit : 0u;
+  out->dummy_ref = w.dummy_ref;
+  out->root_min[0] = root[0].x; out->root_min[1] = root[0].y; out->root_min[2] = root[0].z;
+  out->root_max[0] = root[1].x; out->root_max[1] = root[1].y; out->root_max[2] = root[1].z;
+  outputs.allocs.clear();  // handed over
+  return PTC_OK;
+}
+
+void launch_instance_triangles(hipStream_t stream, const m4& m, const float* d_positions, const uint32_t* d_indices,
+                               const uint32_t* d_tri_order, uint32_t triangles, float4* d_out)
+{
+  if (triangles == 0u) return;
+  hipLaunchKernelGGL(k_lay_instance_tris, dim3((triangles + 255u) / 256u), dim3(256), 0, stream, m, d_positions, d_indices,
+                     d_tri_order, triangles, d_out);
 }
 
 }  // namespace pt

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/ptcore.h"
 #include "pt_math.hpp"
 
@@ -207,9 +209,29 @@ struct DDenoise {
 
 // The reference BVH built on the device (pt_bvh_gpu.hip): the same tree as build_bvh (pt_bvh.cpp), node for node.
 // d_packed: 2 * (2T-1) float4 ({min, first}, {max, count}: DScene::bvh); d_nodes (may be null): the same nodes in the
-// reference's 32-byte layout.  Synchronises the stream (one readback per tree level).
+// reference's 32-byte layout; level_base (may be null): first node of every depth, plus the node count at the end.
+// Synchronises the stream (one readback per tree level).
 int build_bvh_device(hipStream_t stream, const float* d_positions, const uint32_t* d_indices, uint32_t index_count,
-                     float4* d_packed, ptc_bvh_node* d_nodes, uint32_t* node_count, uint32_t* max_depth);
+                     float4* d_packed, ptc_bvh_node* d_nodes, uint32_t* node_count, uint32_t* max_depth,
+                     std::vector<uint32_t>* level_base);
+
+// The traversal layouts of pt_scene_host.cpp (WideAccel, Wide4Accel, the leaf order) built on the device from a
+// reference tree whose nodes are stored depth by depth (level_base as above).  The arrays are hipMalloc'ed and belong
+// to the caller.
+struct DeviceLayouts {
+  uint32_t* nodes_q = nullptr;     // DScene::bvh4q
+  float4* leaf_parent = nullptr;   // DScene::leaf_parent (+ the dummy's entry)
+  uint32_t* tri_order = nullptr;   // depth-first rank -> triangle of the mesh
+  float4* wide = nullptr;          // DScene::wide
+  uint32_t wide4_nodes = 0, wide4_depth = 0, triangles = 0, inner_nodes = 0;
+  uint32_t root_ref4 = 0, root_ref2 = 0, dummy_ref = 0;
+  float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+};
+int build_layouts_device(hipStream_t stream, const float4* d_bvh, uint32_t count, const std::vector<uint32_t>& level_base,
+                         DeviceLayouts* out);
+// world-space triangle records of one instance in depth-first order (DScene::tris), 3 float4 per triangle
+void launch_instance_triangles(hipStream_t stream, const m4& m, const float* d_positions, const uint32_t* d_indices,
+                               const uint32_t* d_tri_order, uint32_t triangles, float4* d_out);
 
 // ---- launch interface (implemented in pt_kernels.hip) ----
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,

@@ -1,5 +1,6 @@
 // pt_scene_host.cpp -- host-side scene flattening helpers (no GPU).
 #include "pt_host.hpp"
+#include "pt_layout_rules.hpp"
 #include "pt_device.hpp"
 
 #include <cmath>
@@ -209,80 +210,12 @@ struct Collapse {
     return 2.0f * (dx * dy + dx * dz + dy * dz);
   }
 
-  // 64-byte form of node idx (Wide4Accel::nodes_q).  Grid: origin = the node's lower corner, step 2^e per axis with
-  // 255 steps covering the node's extent; a child's lower planes round down, its upper planes up (checked in
-  // double precision, where origin + q * step is exact), so the walk over these boxes stays conservative.
-  void quantise(uint32_t idx, int nk, const float lo[3][4], const float hi[3][4], const uint32_t refs[4])
-  {
-    uint32_t* q = &out.nodes_q[(size_t)idx * 16u];
-    uint32_t exps = 0u;
-    for (int a = 0; a < 3; ++a) {
-      float origin = std::numeric_limits<float>::infinity(), top = -std::numeric_limits<float>::infinity();
-      for (int k = 0; k < nk; ++k) {
-        origin = std::min(origin, lo[a][k]);
-        top = std::max(top, hi[a][k]);
-      }
-      const double extent = (double)top - (double)origin;
-      int e = -126;
-      if (extent > 0.0) {
-        e = (int)std::ceil(std::log2(extent / 255.0));
-        e = std::max(-126, std::min(127, e));
-      }
-      for (;;) {  // grow the step until every plane fits 0..255 (one pass almost always)
-        const double step = std::ldexp(1.0, e);
-        bool ok = true;
-        uint32_t lo_q = 0u, hi_q = 0u;
-        for (int k = 0; k < 4; ++k) {
-          // unused slot: an inside-out box (lower planes at the top of the grid, upper planes at its bottom).  Its
-          // slab interval is empty for every ray unless the whole node is smaller than the walk's error bound, and
-          // then the slot's reference leads to the dummy triangle, which no ray hits: the kernel needs no
-          // "is this slot used" test
-          uint32_t ql = 255u, qh = 0u;
-          if (k < nk) {
-            const double fl = std::floor(((double)lo[a][k] - (double)origin) / step);
-            const double ce = std::ceil(((double)hi[a][k] - (double)origin) / step);
-            if (fl < 0.0 || ce > 255.0 || fl > 255.0) ok = false;
-            ql = (uint32_t)std::max(0.0, std::min(255.0, fl));
-            qh = (uint32_t)std::max(0.0, std::min(255.0, ce));
-            if ((double)origin + ql * step > (double)lo[a][k] || (double)origin + qh * step < (double)hi[a][k]) ok = false;
-          }
-          lo_q |= ql << (8 * k);
-          hi_q |= qh << (8 * k);
-        }
-        if (ok || e >= 127) {
-          q[4 + a] = lo_q;
-          q[7 + a] = hi_q;
-          break;
-        }
-        ++e;
-      }
-      std::memcpy(&q[a], &origin, 4);
-      exps |= (uint32_t)(e + 127) << (8 * a);
-    }
-    // the three grid steps as ready-made floats (exponent field only): dword 3 = step x, dwords 10, 11 = step y, z
-    q[3] = (exps & 0xffu) << 23;
-    q[10] = ((exps >> 8) & 0xffu) << 23;
-    q[11] = ((exps >> 16) & 0xffu) << 23;
-    for (int k = 0; k < 4; ++k) q[12 + k] = refs[k];
-  }
-
-  // best[x * 4 + (k - 1)]: least summed area of four-wide nodes when the subtree of reference node x is represented by
-  // at most k roots (a root = a leaf, or an inner node that becomes a four-wide node of its own)
   const std::vector<float>* best_cost = nullptr;
-  float cost(uint32_t x, int k) const { return (*best_cost)[(size_t)x * 4u + (size_t)(k - 1)]; }
-  void expand(uint32_t x, int k, uint32_t kids[4], int& nk) const
-  {
-    if (k <= 1 || nodes[x].primitive_count != 0u || cost(x, k) >= cost(x, 1)) {
-      kids[nk++] = x;
-      return;
-    }
-    const uint32_t l = nodes[x].first_child_or_primitive;
-    int best = 1;
-    for (int j = 2; j < k; ++j)
-      if (cost(l, j) + cost(l + 1u, k - j) < cost(l, best) + cost(l + 1u, k - best)) best = j;
-    expand(l, best, kids, nk);
-    expand(l + 1u, k - best, kids, nk);
-  }
+  struct Tree {
+    const ptc_bvh_node* nodes;
+    bool is_leaf(uint32_t x) const { return nodes[x].primitive_count != 0u; }
+    uint32_t first(uint32_t x) const { return nodes[x].first_child_or_primitive; }
+  };
 
   // returns the child reference of reference-tree node i
   uint32_t emit(uint32_t i, uint32_t level)
@@ -294,15 +227,7 @@ struct Collapse {
     // children: the cut of the subtree into at most four reference nodes that minimises the summed surface area of
     // the four-wide nodes below (the dynamic programme in build_wide4); left-to-right order = depth-first order
     uint32_t kids[4];
-    int nk = 0;
-    {
-      const uint32_t l = nodes[i].first_child_or_primitive;
-      int best = 1;
-      for (int j = 2; j <= 3; ++j)
-        if (cost(l, j) + cost(l + 1u, 4 - j) < cost(l, best) + cost(l + 1u, 4 - best)) best = j;
-      expand(l, best, kids, nk);
-      expand(l + 1u, 4 - best, kids, nk);
-    }
+    const int nk = layout_rules::choose_children(Tree{nodes}, best_cost->data(), i, kids);
     float lo[3][4], hi[3][4];
     uint32_t refs[4];
     for (int k = 0; k < 4; ++k) {
@@ -317,7 +242,7 @@ struct Collapse {
         refs[k] = out.dummy_ref;  // unused slot: see quantise()
       }
     }
-    quantise(idx, nk, lo, hi, refs);
+    layout_rules::quantise_node(&out.nodes_q[(size_t)idx * 16u], nk, lo, hi, refs);
     return idx;
   }
 };
@@ -375,13 +300,7 @@ int build_wide4(const ptc_bvh_node* nodes, uint32_t count, Wide4Accel& out)
     if (nodes[x].primitive_count != 0u) continue;  // a leaf costs nothing here (its test is paid in its parent)
     const float* bl = &best[(size_t)nodes[x].first_child_or_primitive * 4u];
     const float* br = bl + 4;
-    float node_cost = bl[0] + br[2];
-    node_cost = std::min(node_cost, bl[1] + br[1]);
-    node_cost = std::min(node_cost, bl[2] + br[0]);
-    b[0] = Collapse::area(nodes[x]) + node_cost;                       // x as a four-wide node of its own
-    b[1] = std::min(b[0], bl[0] + br[0]);                               // ... or dissolved into 2, 3, 4 roots
-    b[2] = std::min(b[1], std::min(bl[0] + br[1], bl[1] + br[0]));
-    b[3] = std::min(b[2], node_cost);
+    layout_rules::collapse_costs(Collapse::area(nodes[x]), bl, br, b);
   }
   Collapse c{nodes, leaf_rank, out};
   c.best_cost = &best;
@@ -396,17 +315,10 @@ void build_instance_triangles(const m4& m, const float* positions, const uint32_
 {
   for (size_t k = 0; k < tri_order.size(); ++k) {
     const uint32_t* idx = indices + 3u * (size_t)tri_order[k];
-    f3 p[3];
-    for (int v = 0; v < 3; ++v) {
-      const float* q = positions + 3u * (size_t)idx[v];
-      p[v] = xform_point(m, mk3(q[0], q[1], q[2]));
-    }
-    const f3 e1 = p[1] - p[0];
-    const f3 e2 = p[2] - p[0];
-    const f3 n = normalize(cross(e1, e2));
-    out[3u * k] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
-    out[3u * k + 1u] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    out[3u * k + 2u] = make_float4(e2.z, n.x, n.y, n.z);
+    const float* q0 = positions + 3u * (size_t)idx[0];
+    const float* q1 = positions + 3u * (size_t)idx[1];
+    const float* q2 = positions + 3u * (size_t)idx[2];
+    layout_rules::instance_triangle(m, mk3(q0[0], q0[1], q0[2]), mk3(q1[0], q1[1], q1[2]), mk3(q2[0], q2[1], q2[2]), out + 3u * k);
   }
 }
 

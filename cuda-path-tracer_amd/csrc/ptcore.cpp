@@ -165,6 +165,10 @@ struct ptc_ctx {
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
   bool bvh_on_device = true;  // "bvh_build_on_device": the reference BVH of ptc_upload_scene from pt_bvh_gpu.hip
+  bool layout_on_device = true;  // "layout_on_device": the traversal layouts derived from it, too
+  bool build_wide8 = false;      // "build_wide8": the eight-wide tree of trace variant 5 (host-built)
+  bool has_wide8 = false;
+  uint64_t layout_counts[5] = {0, 0, 0, 0, 0};  // bytes of bvh4q, leaf_parent, tris, wide, bvh (ptc_download_layout)
   uint32_t split_idle = 8;    // "split_idle"
   uint32_t min_waves = 1024;  // "min_waves": fewest persistent wavefronts of a traversal launch
   // live paths entering each bounce of one recent frame (what a frame of this scene / camera looks like): the host
@@ -305,21 +309,29 @@ int validate_bvh(ptc_ctx* ctx, const ptc_bvh_node* nodes, uint32_t count, uint32
   return PTC_OK;
 }
 
-// depth of a breadth-first numbered tree (children after parents)
-uint32_t bvh_depth_of(const ptc_bvh_node* nodes, uint32_t count)
+// depth of a tree numbered children-after-parents; level_base (optional) gets the first node of every depth plus the
+// node count when the nodes are stored depth by depth (the reference's breadth-first numbering), else it is left empty
+uint32_t bvh_depth_of(const ptc_bvh_node* nodes, uint32_t count, std::vector<uint32_t>* level_base = nullptr)
 {
   std::vector<uint32_t> depth(count, 0u);
   uint32_t deepest = 0;
+  bool by_level = true;
+  if (level_base) level_base->assign(1, 0u);
   for (uint32_t i = 0; i < count; ++i) {
+    if (depth[i] < deepest) by_level = false;
+    if (depth[i] > deepest && level_base) level_base->push_back(i);
     deepest = std::max(deepest, depth[i]);
     if (nodes[i].primitive_count == 0u) {
       depth[nodes[i].first_child_or_primitive] = depth[i] + 1;
       depth[nodes[i].first_child_or_primitive + 1] = depth[i] + 1;
     }
   }
+  if (level_base) {
+    level_base->push_back(count);
+    if (!by_level || level_base->size() != (size_t)deepest + 2u) level_base->clear();
+  }
   return deepest;
 }
-
 
 int flush_pending(ptc_ctx* ctx);
 
@@ -462,7 +474,7 @@ namespace {
 // The reference BVH of a mesh built on the device.  nodes_host gets the 2T-1 nodes in the reference's layout;
 // *packed_out (when asked for) keeps the device copy in DScene::bvh's layout, owned by the caller.
 int bvh_on_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
-                  ptc_bvh_node* nodes_host, uint32_t* max_depth, float4** packed_out)
+                  ptc_bvh_node* nodes_host, uint32_t* max_depth, float4** packed_out, std::vector<uint32_t>* level_base = nullptr)
 {
   const uint32_t T = index_count / 3u;
   if (T == 0u) return fail(ctx, PTC_ERR_BVH, "empty mesh");
@@ -477,13 +489,13 @@ int bvh_on_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_count, c
   int rc = upload(ctx, pool, &d_pos, positions, (size_t)vertex_count * 3u);
   if (!rc) rc = upload(ctx, pool, &d_idx, indices, (size_t)T * 3u);
   if (!rc) rc = dev_alloc(ctx, pool, &d_packed, 2u * count);
-  if (!rc) rc = dev_alloc(ctx, pool, &d_nodes, count);
+  if (!rc && nodes_host) rc = dev_alloc(ctx, pool, &d_nodes, count);
   uint32_t built = 0u;
   if (!rc) {
-    rc = build_bvh_device(ctx->stream, d_pos, d_idx, T * 3u, d_packed, d_nodes, &built, max_depth);
+    rc = build_bvh_device(ctx->stream, d_pos, d_idx, T * 3u, d_packed, d_nodes, &built, max_depth, level_base);
     if (rc) fail(ctx, rc, rc == PTC_ERR_BVH ? "BVH build failed (empty SAH side: coincident centroids?)" : "device BVH build failed");
   }
-  if (!rc && hipMemcpy(nodes_host, d_nodes, count * sizeof(ptc_bvh_node), hipMemcpyDeviceToHost) != hipSuccess)
+  if (!rc && nodes_host && hipMemcpy(nodes_host, d_nodes, count * sizeof(ptc_bvh_node), hipMemcpyDeviceToHost) != hipSuccess)
     rc = fail(ctx, PTC_ERR_HIP, "device BVH download failed");
   for (void* p : pool)
     if (p != d_packed || rc || !packed_out) (void)hipFree(p);
@@ -506,12 +518,14 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     t_lap = now;
   };
   // bottom-level BVH (scene_description.cpp:99-101), unless the caller brought one
-  std::vector<ptc_bvh_node> built;
-  float4* dev_packed = nullptr;  // the device builder's output, already in DScene::bvh's layout
-  struct Guard {                 // (not leaked by the error returns below)
+  std::vector<ptc_bvh_node> built;   // host copy of a BVH built here (only when something on the host needs it)
+  std::vector<uint32_t> level_base;  // first node of every depth + the node count, when the nodes are stored depth by depth
+  float4* dev_packed = nullptr;      // the device builder's output, already in DScene::bvh's layout
+  struct Guard {                     // (not leaked by the error returns below)
     float4*& p;
     ~Guard() { if (p) (void)hipFree(p); }
   } guard{dev_packed};
+  const bool want_wide8 = ctx->build_wide8 || ctx->trace_variant == 5;
   const ptc_bvh_node* nodes = s->bvh;
   uint32_t node_count = s->bvh ? s->bvh_node_count : 0u;
   uint32_t depth = 0;
@@ -519,27 +533,36 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     nodes = nullptr;
     node_count = 0u;  // the reference panics on an empty mesh (bvh.cpp:200); here it is a scene without mesh
   } else if (!nodes) {
-    built.resize((size_t)s->index_count / 3u * 2u);
     int rc;
     if (ctx->bvh_on_device) {
-      rc = bvh_on_device(ctx, s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth, &dev_packed);
+      const bool host_copy = !ctx->layout_on_device || want_wide8;
+      if (host_copy) built.resize((size_t)s->index_count / 3u * 2u);
+      rc = bvh_on_device(ctx, s->positions, s->vertex_count, s->indices, s->index_count, host_copy ? built.data() : nullptr,
+                         &depth, &dev_packed, &level_base);
       if (rc < 0) return rc;
       times.bvh_on_device = 1u;
+      nodes = host_copy ? built.data() : nullptr;
     } else {
+      built.resize((size_t)s->index_count / 3u * 2u);
       rc = build_bvh(s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth);
       if (rc < 0) return fail(ctx, rc, "BVH build failed (empty SAH side: coincident centroids?)");
+      nodes = built.data();
+      (void)bvh_depth_of(nodes, (uint32_t)rc, &level_base);
     }
     node_count = (uint32_t)rc;
-    nodes = built.data();
   } else {
     if (int rc = validate_bvh(ctx, nodes, node_count, s->index_count)) return rc;
-    depth = bvh_depth_of(nodes, node_count);
+    depth = bvh_depth_of(nodes, node_count, &level_base);
   }
   lap(times.bvh_build_ms);
   if (s->bvh) times.bvh_build_ms = 0.0f;
   // depth-first traversal pushes two children per inner node popped: stack need = depth + 1
   if (node_count && depth + 2u > (uint32_t)kStackDepth)
     return fail(ctx, PTC_ERR_STACK, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack");
+  // the layouts come from the device when the nodes are stored depth by depth (the reference's breadth-first order:
+  // always, unless the caller brought a tree numbered some other way)
+  const bool layouts_on_device = ctx->layout_on_device && node_count != 0u && !level_base.empty();
+  if (!layouts_on_device && node_count != 0u && !nodes) return fail(ctx, PTC_ERR_INVALID, "internal: no host copy of the BVH");
 
   // iterations queued or in flight were asked for against the OLD scene: trace them before it goes away
   if (int rc = sync_frames(ctx)) return rc;
@@ -556,67 +579,110 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.materials = mats;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.positions, s->positions, (size_t)s->vertex_count * 3u)) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.indices, s->indices, s->index_count)) return rc;
-  // node -> two float4: {min.xyz, first}, {max.xyz, count}
-  std::vector<float4> packed(dev_packed ? 0u : (size_t)node_count * 2u);
-  for (uint32_t i = 0; i < node_count && !dev_packed; ++i) {
-    const ptc_bvh_node& n = nodes[i];
-    float fbits, cbits;
-    std::memcpy(&fbits, &n.first_child_or_primitive, 4);
-    std::memcpy(&cbits, &n.primitive_count, 4);
-    packed[2u * i] = make_float4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], fbits);
-    packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
-  }
   if (dev_packed) {
     ctx->scene_allocs.push_back(dev_packed);
     d.bvh = dev_packed;
     dev_packed = nullptr;
-  } else if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) {
-    return rc;
+  } else {
+    // node -> two float4: {min.xyz, first}, {max.xyz, count}
+    std::vector<float4> packed((size_t)node_count * 2u);
+    for (uint32_t i = 0; i < node_count; ++i) {
+      const ptc_bvh_node& n = nodes[i];
+      float fbits, cbits;
+      std::memcpy(&fbits, &n.first_child_or_primitive, 4);
+      std::memcpy(&cbits, &n.primitive_count, 4);
+      packed[2u * i] = make_float4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], fbits);
+      packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
+    }
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) return rc;
   }
   lap(times.copy_ms);
 
-  // layout for the fast traversal: wide inner records + per-instance world-space triangles
-  WideAccel wa;
-  if (int rc = build_wide(nodes, node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
-  lap(times.layout_ms);
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
-  lap(times.copy_ms);
-  // per instance: the mesh's triangles + one all-zero record, the dummy triangle of the four-wide tree's unused
-  // child slots (Wide4Accel::dummy_ref)
-  const size_t inst_tris = wa.tri_order.size() + 1u;
+  // layouts for the fast traversals: wide inner records, the four-wide quantised tree, the triangles of every
+  // instance in depth-first order (+ one all-zero record: the dummy triangle of the four-wide tree's unused slots)
+  const uint32_t mesh_triangles = node_count ? (node_count + 1u) / 2u : 0u;
+  const size_t inst_tris = node_count ? (size_t)mesh_triangles + 1u : 1u;
   std::vector<uint32_t> tri_base(s->object_count, 0u);
   size_t mesh_objects = 0;
   for (uint32_t i = 0; i < s->object_count; ++i)
     if (s->objects[i].type == 1u) tri_base[i] = (uint32_t)(mesh_objects++ * inst_tris);
   if (mesh_objects * inst_tris > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
-  std::vector<float4> tris(mesh_objects * inst_tris * 3u);
-  for (uint32_t i = 0; i < s->object_count; ++i) {
-    if (s->objects[i].type != 1u || wa.tri_order.empty()) continue;
-    m4 m;
-    std::memcpy(&m, s->objects[i].m, sizeof m);
-    build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * 3u);
+  uint32_t w4_depth = 0u, w4_nodes = 0u;
+  if (layouts_on_device) {
+    DeviceLayouts lay;
+    const int rc = build_layouts_device(ctx->stream, d.bvh, node_count, level_base, &lay);
+    for (void* q : {(void*)lay.nodes_q, (void*)lay.leaf_parent, (void*)lay.tri_order, (void*)lay.wide})
+      if (q) ctx->scene_allocs.push_back(q);
+    if (rc) return fail(ctx, rc, "traversal layouts failed on the device");
+    d.wide = lay.wide;
+    d.leaf_parent = lay.leaf_parent;
+    d.bvh4q = reinterpret_cast<const uint4*>(lay.nodes_q);
+    d.bvh4_root = lay.root_ref4;
+    d.dummy_ref = lay.dummy_ref;
+    d.root_ref = lay.root_ref2;
+    std::memcpy(d.root_min, lay.root_min, sizeof d.root_min);
+    std::memcpy(d.root_max, lay.root_max, sizeof d.root_max);
+    w4_depth = lay.wide4_depth;
+    w4_nodes = lay.wide4_nodes;
+    lap(times.layout_ms);
+    float4* tris = nullptr;
+    if (int rc2 = dev_alloc(ctx, ctx->scene_allocs, &tris, mesh_objects * inst_tris * 3u)) return rc2;
+    if (mesh_objects) HIP_TRY(ctx, hipMemsetAsync(tris, 0, mesh_objects * inst_tris * 3u * sizeof(float4), ctx->stream));
+    for (uint32_t i = 0; i < s->object_count; ++i) {
+      if (s->objects[i].type != 1u) continue;
+      m4 m;
+      std::memcpy(&m, s->objects[i].m, sizeof m);
+      launch_instance_triangles(ctx->stream, m, d.positions, d.indices, lay.tri_order, mesh_triangles, tris + (size_t)tri_base[i] * 3u);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    d.tris = tris;
+    lap(times.triangles_ms);
+    times.layout_on_device = 1u;
+  } else {
+    WideAccel wa;
+    if (int rc = build_wide(nodes, node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
+    Wide4Accel w4;
+    if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
+    lap(times.layout_ms);
+    std::vector<float4> tris(mesh_objects * inst_tris * 3u);
+    for (uint32_t i = 0; i < s->object_count; ++i) {
+      if (s->objects[i].type != 1u || wa.tri_order.empty()) continue;
+      m4 m;
+      std::memcpy(&m, s->objects[i].m, sizeof m);
+      build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * 3u);
+    }
+    lap(times.triangles_ms);
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
+    {
+      const uint32_t* q = nullptr;
+      if (int rc = upload(ctx, ctx->scene_allocs, &q, w4.nodes_q.data(), w4.nodes_q.size())) return rc;
+      d.bvh4q = reinterpret_cast<const uint4*>(q);
+    }
+    d.bvh4_root = w4.root_ref;
+    d.dummy_ref = w4.dummy_ref;
+    d.root_ref = wa.root_ref;
+    std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
+    std::memcpy(d.root_max, wa.root_max, sizeof d.root_max);
+    w4_depth = w4.depth;
+    w4_nodes = w4.node_count;
+    lap(times.copy_ms);
   }
-  lap(times.triangles_ms);
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
-  lap(times.copy_ms);
-  Wide4Accel w4;
-  if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
-  lap(times.layout_ms);
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
-  {
-    const uint32_t* q = nullptr;
-    if (int rc = upload(ctx, ctx->scene_allocs, &q, w4.nodes_q.data(), w4.nodes_q.size())) return rc;
-    d.bvh4q = reinterpret_cast<const uint4*>(q);
-  }
-  d.bvh4_root = w4.root_ref;
-  d.dummy_ref = w4.dummy_ref;
-  lap(times.copy_ms);
-  // the eight-wide tree of k_traverse8, its triangle records per instance (own order) and their parent boxes
-  Wide8Accel w8;
-  if (int rc = build_wide8(nodes, node_count, w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
-  lap(times.layout_ms);
-  {
+  ctx->layout_counts[0] = (uint64_t)w4_nodes * 64u;                               // bvh4q
+  ctx->layout_counts[1] = node_count ? ((uint64_t)mesh_triangles + 1u) * 32u : 0u;  // leaf_parent
+  ctx->layout_counts[2] = (uint64_t)mesh_objects * inst_tris * 48u;               // tris
+  ctx->layout_counts[3] = node_count ? ((uint64_t)mesh_triangles - 1u) * 64u : 0u;  // wide
+  ctx->layout_counts[4] = (uint64_t)node_count * 32u;                             // bvh
+  // the eight-wide tree of k_traverse8 (trace variant 5, a cross-check: built on the host, and only when asked for),
+  // its triangle records per instance (own order) and their parent boxes
+  uint32_t w8_depth = 0u;
+  ctx->has_wide8 = false;
+  if (want_wide8 && node_count) {
+    Wide8Accel w8;
+    if (int rc = build_wide8(nodes, node_count, w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
+    lap(times.layout_ms);
     const uint32_t* q = nullptr;
     if (int rc = upload(ctx, ctx->scene_allocs, &q, w8.nodes.data(), w8.nodes.size())) return rc;
     d.bvh8 = reinterpret_cast<const uint4*>(q);
@@ -640,8 +706,10 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     for (size_t k = 0; k < records; ++k) record_of_rank[w8.rank_of_record[k]] = (uint32_t)k;
     if (int rc = upload(ctx, ctx->scene_allocs, &d.record_of_rank8, record_of_rank.data(), record_of_rank.size())) return rc;
     lap(times.copy_ms);
+    w8_depth = w8.depth;
+    ctx->has_wide8 = true;
   }
-  d.bvh8_depth = w8.depth;
+  d.bvh8_depth = w8_depth;
   d.refill_lanes = ctx->refill_lanes;
   d.split_idle = ctx->split_idle;
   d.static_eighths = ctx->static_eighths;
@@ -654,16 +722,13 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   d.lds_cap = ctx->lds_entries;
   if (node_count) {
     // four-wide walk: up to three refs per level; eight-wide walk: one group per level, 12 of them in LDS
-    const uint32_t need4 = 3u * w4.depth + 2u > d.lds_cap ? 3u * w4.depth + 2u - d.lds_cap : 0u;
+    const uint32_t need4 = 3u * w4_depth + 2u > d.lds_cap ? 3u * w4_depth + 2u - d.lds_cap : 0u;
     const uint32_t lds8 = std::min<uint32_t>(d.lds_cap, 12u);
-    const uint32_t need8 = w8.depth + 2u > lds8 ? w8.depth + 2u - lds8 : 0u;
+    const uint32_t need8 = ctx->has_wide8 && w8_depth + 2u > lds8 ? w8_depth + 2u - lds8 : 0u;
     d.spill_cap = std::max(need4, need8);
   }
-  ctx->bvh4_nodes = w4.node_count;
-  ctx->bvh4_depth = w4.depth;
-  std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
-  std::memcpy(d.root_max, wa.root_max, sizeof d.root_max);
-  d.root_ref = wa.root_ref;
+  ctx->bvh4_nodes = w4_nodes;
+  ctx->bvh4_depth = w4_depth;
   d.object_count = s->object_count;
   d.bvh_node_count = node_count;
   // launches of the persistent pipeline (TraceLaunch).  A mesh object without nodes (empty mesh) is no launch; the
@@ -704,6 +769,20 @@ int ptc_build_bvh_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_c
   if (!ctx || !positions || !indices || !nodes || index_count % 3u != 0u) return fail(ctx, PTC_ERR_INVALID, "bad arguments");
   if (int rc = bind_device(ctx)) return rc;
   return bvh_on_device(ctx, positions, vertex_count, indices, index_count, nodes, max_depth, nullptr);
+}
+
+int ptc_download_layout(ptc_ctx* ctx, int which, void* host, uint64_t capacity, uint64_t* bytes)
+{
+  if (!ctx || which < 0 || which > 4) return fail(ctx, PTC_ERR_INVALID, "layout: 0 bvh4q, 1 leaf_parent, 2 tris, 3 wide, 4 bvh");
+  if (!ctx->has_scene) return fail(ctx, PTC_ERR_NO_SCENE, "no scene uploaded");
+  if (int rc = bind_device(ctx)) return rc;
+  const void* src[5] = {ctx->scene.bvh4q, ctx->scene.leaf_parent, ctx->scene.tris, ctx->scene.wide, ctx->scene.bvh};
+  const uint64_t n = ctx->layout_counts[which];
+  if (bytes) *bytes = n;
+  if (!host) return PTC_OK;
+  if (capacity < n) return fail(ctx, PTC_ERR_INVALID, "buffer too small");
+  if (n) HIP_TRY(ctx, hipMemcpy(host, src[which], n, hipMemcpyDeviceToHost));
+  return PTC_OK;
 }
 
 int ptc_get_upload_times(const ptc_ctx* ctx, ptc_upload_times* out)
@@ -905,6 +984,8 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
   if (!ctx || (variant != 0 && variant != 1 && variant != 3 && variant != 5)) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
   if (variant == ctx->trace_variant) return PTC_OK;
+  if (variant == 5 && ctx->has_scene && !ctx->has_wide8 && ctx->scene.bvh_node_count != 0u)
+    return fail(ctx, PTC_ERR_INVALID, "trace variant 5 needs the eight-wide tree: choose it, or set \"build_wide8\", before ptc_upload_scene");
   if (int rc = flush_pending(ctx)) return rc;
   ctx->trace_variant = variant;
   return PTC_OK;
@@ -935,6 +1016,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (std::strcmp(name, "debug_force_slow") == 0) {
     ctx->scene.force_slow = (uint32_t)value;  // 1: every ray at fetch time, 2: every winner at verification time
     ctx->force_slow = value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "layout_on_device") == 0 || std::strcmp(name, "build_wide8") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, std::string(name) + " must be 0 or 1");
+    (name[0] == 'l' ? ctx->layout_on_device : ctx->build_wide8) = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "bvh_build_on_device") == 0) {

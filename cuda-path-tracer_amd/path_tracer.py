@@ -242,7 +242,17 @@ class PathTracer:
         """milliseconds of the last scene upload by stage (ptc_upload_times)"""
         t = _capi.ptc_upload_times()
         self._check(self._lib.ptc_get_upload_times(self._ctx, C.byref(t)))
-        return {k: (int(getattr(t, k)) if k == "bvh_on_device" else round(float(getattr(t, k)), 2)) for k, _ in t._fields_}
+        return {k: (int(getattr(t, k)) if k.endswith("on_device") else round(float(getattr(t, k)), 2)) for k, _ in t._fields_}
+
+    LAYOUTS = {"bvh4q": 0, "leaf_parent": 1, "tris": 2, "wide": 3, "bvh": 4}
+
+    def download_layout(self, which):
+        """bytes of one device-resident traversal array of the uploaded scene (ptc_download_layout)"""
+        n = C.c_uint64(0)
+        self._check(self._lib.ptc_download_layout(self._ctx, self.LAYOUTS[which], None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        self._check(self._lib.ptc_download_layout(self._ctx, self.LAYOUTS[which], out.ctypes.data, n.value, None))
+        return out
 
     def set_trace_variant(self, variant):
         self._check(self._lib.ptc_set_trace_variant(self._ctx, int(variant)))

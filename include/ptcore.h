@@ -200,7 +200,8 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
  *   5           = the same persistent scheme over the tree collapsed to EIGHT children per 80-byte node (children
  *                 in octant slots, visited in the order of the ray's direction signs, one (group, hit mask) stack
  *                 entry per node).  26 % fewer node visits per ray but 45 % more box tests: measured 14 % slower
- *                 than 3 on the benchmark scene; kept as a cross-check and for measurements
+ *                 than 3 on the benchmark scene; kept as a cross-check and for measurements.
+ *                 Its tree is built by ptc_upload_scene only when 5 is selected first or "build_wide8" is set
  *   1           = culled near-first traversal with exact box decisions, one wavefront per 64 fixed paths (the
  *                 walk the default uses for the few rays it sets aside)
  *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no
@@ -218,6 +219,11 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      application that initialises HIP first should export GPU_MAX_HW_QUEUES=24 itself
  *   "bvh_build_on_device"  1 (default): a scene without BVH gets the reference BVH from the GPU builder
  *                      (ptc_build_bvh_device); 0: from the threaded host builder.  Same nodes either way
+ *   "layout_on_device" 1 (default): the traversal layouts (collapsed four-wide tree, leaf order, per-instance
+ *                      triangle records) are derived on the GPU; 0: on the host.  Same bytes either way
+ *                      (ptc_download_layout); a caller's BVH that is not numbered depth by depth goes to the host
+ *   "build_wide8"      1: ptc_upload_scene also builds the eight-wide tree trace variant 5 walks (host-side; default
+ *                      0 unless variant 5 is already selected)
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
@@ -340,8 +346,13 @@ typedef struct ptc_upload_times {
   float copy_ms;        /* hipMalloc + host-to-device copies (includes packing the reference nodes) */
   float total_ms;
   uint32_t bvh_on_device; /* 1: the reference BVH was built by the GPU builder */
+  uint32_t layout_on_device; /* 1: the traversal trees and triangle records were derived on the GPU */
 } ptc_upload_times;
 int ptc_get_upload_times(const ptc_ctx* ctx, ptc_upload_times* out);
+/* The device-resident traversal data of the uploaded scene, for inspection and tests: which = 0 four-wide nodes
+ * (64 B each), 1 parent boxes per triangle rank, 2 per-instance triangle records, 3 two-child records, 4 the reference
+ * nodes as two float4.  *bytes (may be NULL) gets the size; host may be NULL to ask for the size only. */
+int ptc_download_layout(ptc_ctx* ctx, int which, void* host, uint64_t capacity, uint64_t* bytes);
 
 /* bvh_from_mesh (accelerators/bvh.cpp:211-253), host-side, no GPU needed.  nodes must hold
  * index_count/3*2-1 entries.  Returns the node count (>0) or a negative ptc_status. */

@@ -100,3 +100,83 @@ def test_scene_without_bvh_renders_the_same(pkg, on_device):
     assert t1["bvh_on_device"] == on_device and t1["bvh_build_ms"] > 0.0
     assert np.array_equal(got, want) and got_stats["rays_total"] == want_stats["rays_total"]
     assert got_stats["bvh_node_count"] == want_stats["bvh_node_count"] and got_stats["bvh_max_depth"] == want_stats["bvh_max_depth"]
+
+
+def _layouts(pkg, flat, on_device, size=(64, 64)):
+    with pkg.PathTracer() as pt:
+        pt.set_param("layout_on_device", on_device)
+        pt.set_param("bvh_build_on_device", on_device)
+        pt.create_buffers(size, flat)
+        t = pt.upload_times()
+        assert t["layout_on_device"] == (on_device if len(flat.indices) else 0)
+        return {k: pt.download_layout(k) for k in pt.LAYOUTS}, pt.stats()
+
+
+def test_device_layouts_equal_host_layouts(pkg):
+    """The traversal data derived on the GPU -- four-wide quantised nodes in depth-first preorder, parent boxes and
+    triangle records in depth-first leaf order, two-child records -- are byte for byte what pt_scene_host.cpp
+    builds (one source for the decisions: pt_layout_rules.hpp), for meshes of several shapes and instance counts."""
+    glm = pkg.glmlite
+    scenes = []
+    for name, mesh in _meshes(pkg):
+        sc = pkg.SceneDescription()
+        sc.add_material("m", pkg.DiffuseMateral((0.5, 0.5, 0.5)))
+        sc.add_mesh(name, mesh)
+        sc.add_object(mesh, glm.compose([glm.translate((0.5, -1.0, 2.0))]), "m")
+        if name in ("sphere24x48", "soup5"):   # a second, rotated and non-uniformly scaled instance
+            sc.add_object(mesh, glm.compose([glm.rotate(np.float32(0.6), (0.3, 1.0, 0.2)), glm.scale((0.7, 0.4, 0.9))]), "m")
+        scenes.append((name, sc))
+    scenes.append(("cornell_bunny", pkg.scenes.cornell_bunny((64, 64))))
+    scenes.append(("spheres_only", pkg.scenes.cornell_spheres((64, 64))))
+    for name, sc in scenes:
+        flat = sc.build_scene()
+        dev, dev_stats = _layouts(pkg, flat, 1)
+        host, host_stats = _layouts(pkg, flat, 0)
+        for k in dev:
+            assert dev[k].shape == host[k].shape and np.array_equal(dev[k], host[k]), (name, k)
+        assert dev_stats["bvh_node_count"] == host_stats["bvh_node_count"], name
+        assert dev_stats["stack_capacity"] == host_stats["stack_capacity"], name
+
+
+def test_device_layouts_benchmark_mesh(pkg):
+    flat = pkg.scenes.heightfield_scene((64, 64)).build_scene()
+    dev, _ = _layouts(pkg, flat, 1)
+    host, _ = _layouts(pkg, flat, 0)
+    assert len(dev["bvh"]) == 1_999_999 * 32 and len(dev["tris"]) == 1_000_001 * 48
+    for k in dev:
+        assert np.array_equal(dev[k], host[k]), k
+
+
+def test_caller_bvh_in_another_order_goes_to_the_host(pkg):
+    """a caller's BVH numbered children-after-parents but not depth by depth: the layouts come from the host code"""
+    scene = pkg.scenes.heightfield_scene((96, 64), nx=33, nz=17)
+    mesh = list(scene.mesh_map_.values())[0]
+    nodes, _ = pkg.bvh_from_mesh(mesh)
+    # renumber depth-first: children still follow their parent and stay adjacent; same topology, same image
+    res = [nodes[0].copy()]
+    work = [(0, 0)]
+    while work:
+        src, dst = work.pop()
+        if nodes[src]["primitive_count"] == 0:
+            f = nodes[src]["first_child_or_primitive"]
+            at = len(res)
+            res.append(nodes[f].copy()); res.append(nodes[f + 1].copy())
+            res[dst]["first_child_or_primitive"] = at
+            work.append((f + 1, at + 1)); work.append((f, at))
+    shuffled = np.array(res, dtype=nodes.dtype)
+    flat = scene.build_scene()
+    a = copy.copy(flat); a.bvh = nodes
+    b = copy.copy(flat); b.bvh = shuffled
+
+    def render(f):
+        with pkg.PathTracer(device=0, max_bounces=5) as pt:
+            pt.create_buffers((96, 64), f)
+            t = pt.upload_times()
+            for _ in range(2):
+                pt.path_trace(scene.camera)
+            return pt.download("color"), t
+
+    img_a, t_a = render(a)
+    img_b, t_b = render(b)
+    assert t_a["layout_on_device"] == 1 and t_b["layout_on_device"] == 0
+    assert np.array_equal(img_a, img_b)

@@ -18,6 +18,8 @@ def frames(pkg, scene, flat, w, h, iters, mb, variant=None, fif=None, params=())
             pt.set_param("frames_in_flight", fif)
         for k, v in params:
             pt.set_param(k, v)
+        if variant == 5:
+            pt.set_param("build_wide8", 1)   # the eight-wide tree is built only on request
         pt.create_buffers((w, h), flat)
         if variant is not None:
             pt.set_trace_variant(variant)
@@ -410,6 +412,7 @@ def test_benchmark_size_rays_against_oracle(pkg, orc, big):
     m = hit.astype(bool)
     assert 0.3 < m.mean() < 0.99
     with pkg.PathTracer() as pt:
+        pt.set_param("build_wide8", 1)
         pt.create_buffers((64, 64), flat)
         for variant in (3, 5, 0, 1):
             pt.set_trace_variant(variant)
@@ -463,6 +466,7 @@ def test_instance_ties_and_carried_hits(pkg, orc):
     # test compared with t_max, path_tracer.cu:93-94, so a few of those may flip: whatever the oracle says)
     assert m[n:n + len(again)].mean() > 0.9
     with pkg.PathTracer() as pt:
+        pt.set_param("build_wide8", 1)
         pt.create_buffers((32, 32), flat)
         for variant in (3, 5, 0, 1):
             pt.set_trace_variant(variant)
