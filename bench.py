@@ -165,8 +165,12 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     flat = scene.build_scene()
     mesh = list(scene.mesh_map_.values())[0]
     t0 = time.perf_counter()
-    flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)
+    flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)       # host builder: the tree the CPU oracle walks (parity, cpu_baseline)
     bvh_build_s = time.perf_counter() - t0
+    import copy
+    bare = copy.copy(flat)
+    bare.bvh = None   # the tracer gets the scene as the reference's front end hands it over: the library builds BVH and layouts (on the GPU)
+    startup = {}
     rank_rows = pkg.bands.interleaved_rows(H, world, BLOCK_ROWS)
 
     # Schedule: `batch` consecutive frames share every launch (the latency tail of a bounce -- a few long rays --
@@ -195,7 +199,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.set_param("ray_sort", args.ray_sort)
         if args.trace_variant >= 0:
             pt.set_trace_variant(args.trace_variant)
-        pt.create_buffers((W, H), flat)
+        pt.create_buffers((W, H), bare)
+        startup.update(pt.upload_times())
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
         if world > 1:
             pt.set_interleave(rank, world, BLOCK_ROWS)
@@ -379,7 +384,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                    "live_per_bounce_last_frame_rank0": last_live, "exact_redo_rays": slow_rays,
                    "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks; "
                                 f"present-time gather: {args.gather}",
-                   "bvh_build_s": round(bvh_build_s, 3)},
+                   "startup": {"scene_upload_ms": startup, "note": "ptc_upload_scene of the scene without BVH: reference BVH (bit-identical "
+                               "to the host builder's) and traversal layouts built on the GPU", "host_bvh_builder_s": round(bvh_build_s, 3)}},
         "roofline": roofline,
         "parity": parity,
         "steady_state": steady,

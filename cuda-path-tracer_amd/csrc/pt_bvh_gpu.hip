@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_lay_instance_tris(m4 m, const float* po
   const float* q0 = positions + 3u * (size_t)idx[0];
   const float* q1 = positions + 3u * (size_t)idx[1];
   const float* q2 = positions + 3u * (size_t)idx[2];
-  layout_rules::instance_triangle(m, mk3(q0[0], q0[1], q0[2]), mk3(q1[0], q1[1], q1[2]), mk3(q2[0], q2[1], q2[2]), out + 3u * (size_t)k);
+  layout_rules::instance_triangle(m, mk3(q0[0], q0[1], q0[2]), mk3(q1[0], q1[1], q1[2]), mk3(q2[0], q2[1], q2[2]), out + kTriVec4 * (size_t)k);
 }
 
 }  // namespace

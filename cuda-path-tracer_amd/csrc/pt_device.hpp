@@ -45,7 +45,8 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //           w0 = {lmin.xyz, lmax.x}  w1 = {lmax.yz, rmin.xy}  w2 = {rmin.z, rmax.xyz}  w3 = {bits lref, bits rref, -, -}
 //         ref = index of the child's record, or kLeafBit | rank of the child's triangle in depth-first
 //         (left-first) leaf order -- the order in which the reference's traversal reaches the leaves.
-//   tris: per MESH OBJECT (instance), world-space triangles in that depth-first order, three float4 each:
+//   tris: per MESH OBJECT (instance), world-space triangles in that depth-first order, kTriVec4 (= 4) float4 each,
+//         three of them used:
 //           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, n.xyz}   with p = transform_point(M, position),
 //           e1 = p1 - p0, e2 = p2 - p0, n = normalize(cross(e1, e2))   (exactly what the reference
 //           recomputes per test, path_tracer.cu:57-59, intersections.cuh:45-46,54-55)
@@ -71,6 +72,12 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //   tris8: per MESH OBJECT, world-space triangle records in bvh8's record order, three float4 each:
 //           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(depth-first rank), -, -}   (the normal is recomputed for the winner)
 //   leaf_parent8: leaf_parent in that record order.
+// float4s per triangle record of DScene::tris: the 48 bytes described above padded to 64, so that a record never
+// straddles two 64-byte segments of a cache line (measured +2 % rays/s against 48-byte records; 3 = unpadded)
+#ifndef PT_TRI_VEC4
+#define PT_TRI_VEC4 4
+#endif
+constexpr uint32_t kTriVec4 = PT_TRI_VEC4;
 constexpr int kNode8Dwords = 20;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
@@ -84,7 +91,7 @@ struct DScene {
   const uint32_t* indices;
   const float4* bvh;
   const float4* wide;              // 4 float4 per inner node
-  const float4* tris;              // 3 float4 per instance triangle
+  const float4* tris;              // kTriVec4 float4 per instance triangle
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
   const float4* leaf_parent;       // 2 float4 per triangle
   const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
@@ -229,7 +236,7 @@ struct DeviceLayouts {
 };
 int build_layouts_device(hipStream_t stream, const float4* d_bvh, uint32_t count, const std::vector<uint32_t>& level_base,
                          DeviceLayouts* out);
-// world-space triangle records of one instance in depth-first order (DScene::tris), 3 float4 per triangle
+// world-space triangle records of one instance in depth-first order (DScene::tris), kTriVec4 float4 per triangle
 void launch_instance_triangles(hipStream_t stream, const m4& m, const float* d_positions, const uint32_t* d_indices,
                                const uint32_t* d_tri_order, uint32_t triangles, float4* d_out);
 

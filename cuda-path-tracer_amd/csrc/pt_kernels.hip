@@ -376,13 +376,13 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
     if (exact_only) slab_cull(ld3(sc.root_min), ld3(sc.root_max), oo, inv, tn, tf);
     if (box_culled(tn, tf, limit)) return;
   }
-  const float4* tris = sc.tris + 3u * (size_t)tri_base;
+  const float4* tris = sc.tris + kTriVec4 * (size_t)tri_base;
   int sp = 0;
   for (;;) {
     if (cur & kLeafBit) {
       // ray_triangle_intersection_test (intersections.cuh:49-85) on the precomputed world-space edges
       const uint32_t k = cur & ~kLeafBit;
-      const float4 ta = tris[3u * k], tb = tris[3u * k + 1u], tc = tris[3u * k + 2u];
+      const float4 ta = tris[kTriVec4 * k], tb = tris[kTriVec4 * k + 1u], tc = tris[kTriVec4 * k + 2u];
       if (kCount) ++tally.tris;
       const f3 p0 = mk3(ta.x, ta.y, ta.z), e1 = mk3(ta.w, tb.x, tb.y), e2 = mk3(tb.z, tb.w, tc.x);
       const f3 h = cross(ray.d, e2);
@@ -516,7 +516,7 @@ __device__ __forceinline__ bool ray_scene_wide(Ray ray, const DScene& sc, Hit& r
     }
   }
   if (win_tri >= 0) {
-    const float4 tc = sc.tris[3u * (size_t)win_tri + 2u];
+    const float4 tc = sc.tris[kTriVec4 * (size_t)win_tri + 2u];
     const f3 outward = mk3(tc.y, tc.z, tc.w);
     rec.p = ray_at(ray, rec.t);
     rec.side = dot(ray.d, outward) < 0.0f ? 0u : 1u;
@@ -949,7 +949,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   if (n_max == 0u) return;
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
-  const float4* tris = sc.tris + 3u * (size_t)sc.object_tri_base[obj_index];
+  const float4* tris = sc.tris + kTriVec4 * (size_t)sc.object_tri_base[obj_index];
   // more wavefronts than batches (the margin keeps every wavefront that owns a static batch, see BatchFeed)
   if (blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
   // the object's world box: the same for every ray of the launch (scalar registers)
@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     // dependent round trips otherwise: this code runs every few loop iterations)
     const size_t win = (size_t)max(best_k, 0);
     const float4 pb0 = sc.leaf_parent[2u * win], pb1 = sc.leaf_parent[2u * win + 1u];
-    const float4 tc = tris[3u * win + 2u];
+    const float4 tc = tris[kTriVec4 * win + 2u];
     if (best_k >= 0) {
       // world box (ray_aabb, intersections.cuh:87-103): quotients by reciprocal, each within 3 ulp of the quotient
       const f3 bmin = obj_bmin, bmax = obj_bmax;
@@ -1254,8 +1254,6 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     if (active) {
       const bool is_leaf = (cur & kLeafBit) != 0u;
       const uint32_t index = cur & ~kLeafBit;
-      const char* rec = is_leaf ? reinterpret_cast<const char*>(tris) + 48u * (size_t)index
-                                : reinterpret_cast<const char*>(sc.bvh4q) + 64u * (size_t)index;
       // The four loads are written as instructions: left to the compiler they are split by use (the leaf branch
       // needs 36 of the 64 bytes), narrowed and partly sunk into the branches -- five to seven loads again.  The
       // compiler does not count these in its s_waitcnt bookkeeping, so the wait is explicit and carries the four
@@ -1263,13 +1261,26 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       // vmcnt waits elsewhere stay conservative.)
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       u32x4 w0, w1, w2, w3;
-      const char* rec3 = rec + (is_leaf ? 32 : 48);
+      // The compiler's own wait bookkeeping does not see the explicit waits of earlier iterations either: a load it
+      // issued itself long ago (ray fetch, finalize) can still count as "in flight" on some path into this block,
+      // and the wait it then inserts in front of the first instruction that touches the register lands wherever
+      // register allocation puts that register -- between the four loads below in two measured builds (each load
+      // then waits for the one before: 17 % slower).  A wait it does understand, here, where nothing is in flight,
+      // clears its books for the whole group.
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      // (the "fourth quarter" of a 48-byte triangle record would be the head of the next record: its last 16 bytes
+      // are requested twice instead; a 64-byte record is simply read whole)
+      constexpr bool kLeaf48 = kTriVec4 == 3u;
+      const char* rec = is_leaf ? reinterpret_cast<const char*>(tris) + (16u * kTriVec4) * (size_t)index
+                                : reinterpret_cast<const char*>(sc.bvh4q) + 64u * (size_t)index;
+      const char* rec3 = rec + (kLeaf48 && is_leaf ? 32 : 48);
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w0) : "v"(rec));
       asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(w1) : "v"(rec));
       asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(w2) : "v"(rec));
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w3) : "v"(rec3));
       const uint32_t below = peek();
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the four loads have landed (a wait the compiler's bookkeeping sees)
+      asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));  // ... and nothing reads them above this line
       const uint4 q0 = make_uint4(w0.x, w0.y, w0.z, w0.w), q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
       const uint4 q2 = make_uint4(w2.x, w2.y, w2.z, w2.w), q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
       if (!is_leaf) {
@@ -1430,7 +1441,7 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
     if (ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax)))
       mesh_closest_wide<false>(ray, sc, obj, tri_base, best_t, best_k, sc.slow_stack + threadIdx.x, flags, unused);
     if (best_k >= 0) {
-      const float4 tc = sc.tris[3u * ((size_t)tri_base + (uint32_t)best_k) + 2u];
+      const float4 tc = sc.tris[kTriVec4 * ((size_t)tri_base + (uint32_t)best_k) + 2u];
       const f3 outward = mk3(tc.y, tc.z, tc.w);
       const f3 p = ray.o + ray.d * best_t;
       const uint32_t side = dot(ray.d, outward) < 0.0f ? 0u : 1u;

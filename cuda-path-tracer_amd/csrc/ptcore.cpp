@@ -626,13 +626,14 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     w4_nodes = lay.wide4_nodes;
     lap(times.layout_ms);
     float4* tris = nullptr;
-    if (int rc2 = dev_alloc(ctx, ctx->scene_allocs, &tris, mesh_objects * inst_tris * 3u)) return rc2;
-    if (mesh_objects) HIP_TRY(ctx, hipMemsetAsync(tris, 0, mesh_objects * inst_tris * 3u * sizeof(float4), ctx->stream));
+    const size_t tri_vec4 = mesh_objects * inst_tris * kTriVec4;
+    if (int rc2 = dev_alloc(ctx, ctx->scene_allocs, &tris, tri_vec4)) return rc2;
+    if (tri_vec4) HIP_TRY(ctx, hipMemsetAsync(tris, 0, tri_vec4 * sizeof(float4), ctx->stream));
     for (uint32_t i = 0; i < s->object_count; ++i) {
       if (s->objects[i].type != 1u) continue;
       m4 m;
       std::memcpy(&m, s->objects[i].m, sizeof m);
-      launch_instance_triangles(ctx->stream, m, d.positions, d.indices, lay.tri_order, mesh_triangles, tris + (size_t)tri_base[i] * 3u);
+      launch_instance_triangles(ctx->stream, m, d.positions, d.indices, lay.tri_order, mesh_triangles, tris + (size_t)tri_base[i] * kTriVec4);
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     d.tris = tris;
@@ -644,17 +645,17 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     Wide4Accel w4;
     if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
     lap(times.layout_ms);
-    std::vector<float4> tris(mesh_objects * inst_tris * 3u);
+    std::vector<float4> tris(mesh_objects * inst_tris * kTriVec4);
     for (uint32_t i = 0; i < s->object_count; ++i) {
       if (s->objects[i].type != 1u || wa.tri_order.empty()) continue;
       m4 m;
       std::memcpy(&m, s->objects[i].m, sizeof m);
-      build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * 3u);
+      build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * kTriVec4);
     }
     lap(times.triangles_ms);
     if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
     if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
     {
       const uint32_t* q = nullptr;
       if (int rc = upload(ctx, ctx->scene_allocs, &q, w4.nodes_q.data(), w4.nodes_q.size())) return rc;
@@ -672,7 +673,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
   ctx->layout_counts[0] = (uint64_t)w4_nodes * 64u;                               // bvh4q
   ctx->layout_counts[1] = node_count ? ((uint64_t)mesh_triangles + 1u) * 32u : 0u;  // leaf_parent
-  ctx->layout_counts[2] = (uint64_t)mesh_objects * inst_tris * 48u;               // tris
+  ctx->layout_counts[2] = (uint64_t)mesh_objects * inst_tris * 16u * kTriVec4;               // tris
   ctx->layout_counts[3] = node_count ? ((uint64_t)mesh_triangles - 1u) * 64u : 0u;  // wide
   ctx->layout_counts[4] = (uint64_t)node_count * 32u;                             // bvh
   // the eight-wide tree of k_traverse8 (trace variant 5, a cross-check: built on the host, and only when asked for),

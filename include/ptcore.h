@@ -350,7 +350,7 @@ typedef struct ptc_upload_times {
 } ptc_upload_times;
 int ptc_get_upload_times(const ptc_ctx* ctx, ptc_upload_times* out);
 /* The device-resident traversal data of the uploaded scene, for inspection and tests: which = 0 four-wide nodes
- * (64 B each), 1 parent boxes per triangle rank, 2 per-instance triangle records, 3 two-child records, 4 the reference
+ * (64 B each), 1 parent boxes per triangle rank, 2 per-instance triangle records (64 B each), 3 two-child records, 4 the reference
  * nodes as two float4.  *bytes (may be NULL) gets the size; host may be NULL to ask for the size only. */
 int ptc_download_layout(ptc_ctx* ctx, int which, void* host, uint64_t capacity, uint64_t* bytes);
 

@@ -142,7 +142,7 @@ def test_device_layouts_benchmark_mesh(pkg):
     flat = pkg.scenes.heightfield_scene((64, 64)).build_scene()
     dev, _ = _layouts(pkg, flat, 1)
     host, _ = _layouts(pkg, flat, 0)
-    assert len(dev["bvh"]) == 1_999_999 * 32 and len(dev["tris"]) == 1_000_001 * 48
+    assert len(dev["bvh"]) == 1_999_999 * 32 and len(dev["tris"]) == 1_000_001 * 64
     for k in dev:
         assert np.array_equal(dev[k], host[k]), k
 
