@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--traverse-waves", type=int, default=0, help="persistent wavefronts of a full-size traversal launch (0 = tuned default)")
     ap.add_argument("--ray-sort", type=int, default=0, help="1: direction-octant ray sorting of the pick-up order (config.ray_sort)")
     ap.add_argument("--trace-variant", type=int, default=-1, help="closest-hit kernel (-1 = the library's default; 3 four-wide, 5 eight-wide tree)")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="extra ptc_set_param before the scene upload (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
     ap.add_argument("--gather", choices=("rccl", "ipc"), default="rccl",
@@ -199,6 +200,9 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.set_param("ray_sort", args.ray_sort)
         if args.trace_variant >= 0:
             pt.set_trace_variant(args.trace_variant)
+        for kv in args.param:
+            name, value = kv.split("=")
+            pt.set_param(name, int(value))
         pt.create_buffers((W, H), bare)
         startup.update(pt.upload_times())
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
