@@ -16,7 +16,8 @@ def main(path, by_grid=False):
     print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
     print(f"{'kernel':<70} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>10} {'%':>6} {'vgpr':>5} {'sgpr':>5} {'lds':>6} {'wg':>5}")
     for name, calls, tot, avg, mn, mx, vg, sg, lds, wg in rows:
-        short = (name.split("(")[0] + (name[name.rindex(" grid "):] if by_grid else ""))[-70:]
+        base = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        short = (base.split("(")[0] + (name[name.rindex(" grid "):] if by_grid else ""))[-70:]
         print(f"{short:<70} {calls:>6} {tot / 1e6:>10.3f} {avg / 1e3:>10.2f} {mn / 1e3:>9.2f} {mx / 1e3:>10.2f} "
               f"{100.0 * tot / total:>6.2f} {vg:>5} {sg:>5} {lds:>6} {wg:>5}")
 
