@@ -109,8 +109,9 @@ def pmc_record(name, frames_per_launch):
     return rec
 
 
-def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
-    """SURVEY 8(d) pricing of the closest-hit launches of the timed region."""
+def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, pmc_scene=True):
+    """SURVEY 8(d) pricing of the closest-hit launches of the timed region.  pmc_scene: the counter records under
+    profiles/ were taken on THIS scene (config 3); otherwise traffic / valu are null."""
     scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
     rays = sum(paths_timed)
     nodes = sum(scale[b] * counted["node_visits"][b] for b in range(MB))
@@ -121,8 +122,9 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
     trace_ms = sum(prof["trace_ms"])
     launches = sum(prof["trace_launches"])
     achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    traffic_rec = pmc_record("pmc_traffic_%d.json", frames_per_launch)
-    traffic = note = None
+    traffic_rec = pmc_record("pmc_traffic_%d.json", frames_per_launch) if pmc_scene else None
+    traffic = None
+    note = None if pmc_scene else "null: no counter record for this scene (profiles/pmc_*.json are config 3)"
     if traffic_rec is not None:
         if traffic_rec["matches_this_run"]:
             traffic = traffic_rec.get("trace_kernel_hbm_bytes_per_launch")
@@ -150,7 +152,7 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch):
         "note": "the kernel's working set (27 MB of nodes + 48 MB of triangles + path state of the batch) is served "
                 "by L2 / Infinity Cache; it is bound by VALU issue at about half lane utilisation, see valu",
     }
-    sq = pmc_record("pmc_sq_%d.json", frames_per_launch)
+    sq = pmc_record("pmc_sq_%d.json", frames_per_launch) if pmc_scene else None
     if sq is not None:
         roof["valu"] = {k: sq.get(k) for k in ("valu_busy_frac", "valu_pipe_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
                                                 "salu_inst_per_ray", "l2_hit_frac", "wave_occupancy_frac", "frames_per_launch",
@@ -439,8 +441,9 @@ def run_config2(args, pkg, torch, local_rank):
         pt.path_trace(scene.camera)
     counted = pt.profile()
     pt.set_profiling(False, False)
-    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch)
+    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=False)
     roofline["kernel"] += "; one launch per mesh instance and bounce"
+    roofline["note"] = "3.3 node visits per ray: ray fetch, hit write and the per-launch tails weigh more than in config 3"
     pt.close()
     cpu_baseline = None
     if not args.no_cpu_baseline:
