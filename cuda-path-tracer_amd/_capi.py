@@ -46,6 +46,11 @@ class ptc_bvh_node(C.Structure):
                 ("first_child_or_primitive", C.c_uint32), ("primitive_count", C.c_uint32)]
 
 
+class ptc_mesh_range(C.Structure):
+    _fields_ = [("first_vertex", C.c_uint32), ("vertex_count", C.c_uint32), ("first_index", C.c_uint32),
+                ("index_count", C.c_uint32), ("first_bvh_node", C.c_uint32), ("bvh_node_count", C.c_uint32)]
+
+
 class ptc_scene_desc(C.Structure):
     _fields_ = [("objects", C.POINTER(ptc_object)), ("object_count", C.c_uint32),
                 ("object_material_indices", C.POINTER(C.c_uint32)),
@@ -53,7 +58,8 @@ class ptc_scene_desc(C.Structure):
                 ("materials", C.POINTER(ptc_material)), ("material_count", C.c_uint32),
                 ("positions", C.POINTER(C.c_float)), ("vertex_count", C.c_uint32),
                 ("indices", C.POINTER(C.c_uint32)), ("index_count", C.c_uint32),
-                ("bvh", C.POINTER(ptc_bvh_node)), ("bvh_node_count", C.c_uint32)]
+                ("bvh", C.POINTER(ptc_bvh_node)), ("bvh_node_count", C.c_uint32),
+                ("meshes", C.POINTER(ptc_mesh_range)), ("mesh_count", C.c_uint32)]
 
 
 class ptc_camera(C.Structure):

@@ -82,42 +82,51 @@ constexpr int kNode8Dwords = 20;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
 
+// The acceleration data of ONE mesh (reference tree + the traversal layouts derived from it).  DScene::cur is the
+// mesh of the object a traversal launch walks (the host sets it per launch); kernels that loop over all objects of
+// the scene look the mesh up per object (DScene::mesh_views[DScene::object_mesh[i]]).
+struct DMeshView {
+  const float* positions;
+  const uint32_t* indices;
+  const float4* bvh;
+  const float4* wide;              // 4 float4 per inner node
+  const float4* leaf_parent;       // 2 float4 per triangle
+  const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
+  const uint4* bvh8;               // the eight-wide nodes in 80 bytes (Wide8Accel::nodes), 5 x uint4 per node
+  const float4* leaf_parent8;      // 2 float4 per triangle record
+  const uint32_t* record_of_rank8; // depth-first rank -> triangle record (work splitting: another lane's candidate)
+  uint32_t bvh8_depth;
+  uint32_t bvh4_root;
+  uint32_t dummy_ref;              // reference in the unused child slots of a four-wide node (an inside-out box, a triangle no ray hits)
+  float root_min[3];               // box of the root (tested before descending, like any inner node)
+  float root_max[3];
+  uint32_t root_ref;               // record 0, or kLeafBit for a single-triangle mesh
+  uint32_t bvh_node_count;
+};
+
 struct DScene {
   const DObject* objects;
   const uint32_t* object_material;
   const float4* spheres;  // center.xyz, radius
   const DMaterial* materials;
-  const float* positions;
-  const uint32_t* indices;
-  const float4* bvh;
-  const float4* wide;              // 4 float4 per inner node
+  DMeshView cur;                   // the mesh of this launch's object (mesh 0 unless the host says otherwise)
+  const DMeshView* mesh_views;     // all meshes of the scene ...
+  const uint32_t* object_mesh;     // ... and which one each object instantiates (0 for spheres)
   const float4* tris;              // kTriVec4 float4 per instance triangle
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
-  const float4* leaf_parent;       // 2 float4 per triangle
-  const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
-  const uint4* bvh8;               // the eight-wide nodes in 80 bytes (Wide8Accel::nodes), 5 x uint4 per node
   const float4* tris8;             // 3 float4 per instance triangle, bvh8's record order
-  const float4* leaf_parent8;      // 2 float4 per triangle record
   const uint32_t* object_tri_base8; // per object: first record of its instance in `tris8`
-  const uint32_t* record_of_rank8;  // depth-first rank -> triangle record (work splitting: another lane's candidate)
-  uint32_t bvh8_depth;
   uint32_t* slow_stack;            // global traversal stack of the launch's exact redo (redo_slow_rays), [kStackDepth][kWave]
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
   uint32_t spill_cap;              // entries per thread in `spill`
   uint32_t lds_cap;                // entries per lane kept in LDS before `spill` (kLds4; fewer only in tests)
-  uint32_t bvh4_root;
-  uint32_t dummy_ref;              // reference in the unused child slots of a four-wide node (an inside-out box, a triangle no ray hits)
   uint32_t force_slow;             // test hook: hand EVERY ray to the exact redo (redo_slow_rays)
   uint32_t static_eighths;         // persistent traversal: share (x/8) of each image region dealt without atomics
   uint32_t refill_lanes;           // persistent traversal: fetch new rays once this many lanes of a wavefront are idle
   uint32_t split_idle;             // ... and once the launch has no rays left: split busy lanes' stacks among idle ones when
                                    // at least this many lanes are idle (0: never)
-  float root_min[3];               // box of the root (tested before descending, like any inner node)
-  float root_max[3];
-  uint32_t root_ref;               // record 0, or kLeafBit for a single-triangle mesh
   uint32_t object_count;
-  uint32_t bvh_node_count;
 };
 
 // Camera constants prepared on the host once per frame (GPUCamera, camera.hpp:10-15, plus the

@@ -183,13 +183,13 @@ __device__ __forceinline__ void inverse_transform_ray(const m4& inv_m, const Ray
 // the line crosses is entered (the reference has no t culling).  The stack lives in LDS, laid out
 // [depth][lane] so that a push or pop of the whole wavefront touches 64 consecutive banks.
 template <bool kCount>
-__device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObject* obj, Hit& rec, uint32_t* stack,
+__device__ __forceinline__ bool ray_mesh(Ray ray, const DMeshView& mv, const DObject* obj, Hit& rec, uint32_t* stack,
                                          uint32_t& flags, Tally& tally, const int stack_cap = kStackDepth)
 {
   bool hit = false;
   f3 oo, od;
   inverse_transform_ray(obj->inv_m, ray, oo, od);
-  if (sc.bvh_node_count == 0u) return false;
+  if (mv.bvh_node_count == 0u) return false;
 
   int sp = 0;
   stack[0] = 0u;
@@ -197,15 +197,15 @@ __device__ __forceinline__ bool ray_mesh(Ray ray, const DScene& sc, const DObjec
   while (sp > 0) {
     --sp;
     const uint32_t node = stack[sp * kWave];
-    const float4 n0 = sc.bvh[2u * node];
-    const float4 n1 = sc.bvh[2u * node + 1u];
+    const float4 n0 = mv.bvh[2u * node];
+    const float4 n1 = mv.bvh[2u * node + 1u];
     const uint32_t first = __float_as_uint(n0.w);
     const uint32_t count = __float_as_uint(n1.w);
     if (count != 0u) {
-      const uint32_t i0 = sc.indices[first], i1 = sc.indices[first + 1u], i2 = sc.indices[first + 2u];
-      const f3 p0 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i0));
-      const f3 p1 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i1));
-      const f3 p2 = xform_point(obj->m, ld3(sc.positions + 3u * (size_t)i2));
+      const uint32_t i0 = mv.indices[first], i1 = mv.indices[first + 1u], i2 = mv.indices[first + 2u];
+      const f3 p0 = xform_point(obj->m, ld3(mv.positions + 3u * (size_t)i0));
+      const f3 p1 = xform_point(obj->m, ld3(mv.positions + 3u * (size_t)i1));
+      const f3 p2 = xform_point(obj->m, ld3(mv.positions + 3u * (size_t)i2));
       if (kCount) ++tally.tris;
       if (ray_triangle(ray, p0, p1, p2, rec)) {
         hit = true;
@@ -247,7 +247,7 @@ __device__ __forceinline__ bool ray_scene(Ray ray, const DScene& sc, Hit& rec, u
         rec.n = xform_normal(obj->inv_m, rec.n);
       }
     } else {
-      h = ray_mesh<kCount>(ray, sc, obj, rec, stack, flags, tally);
+      h = ray_mesh<kCount>(ray, sc.mesh_views[sc.object_mesh[i]], obj, rec, stack, flags, tally);
     }
     if (h) {
       hit = true;
@@ -354,11 +354,11 @@ __device__ __forceinline__ bool box_culled(const float t_near, const float t_far
 }
 
 template <bool kCount>
-__device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& sc, const DObject* obj,
+__device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& sc, const DMeshView& mv, const DObject* obj,
                                                   const uint32_t tri_base, float& best_t, int& best_k, uint32_t* stack,
                                                   uint32_t& flags, Tally& tally)
 {
-  if (sc.bvh_node_count == 0u) return;
+  if (mv.bvh_node_count == 0u) return;
   // inverse_transform_ray (transform.hpp:51-58); scale = length before the re-normalisation
   const f3 v = xform_vector(obj->inv_m, ray.d);
   const float scale = ieee_sqrt(dot(v, v));
@@ -368,12 +368,12 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
   const bool exact_only = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z));
   float limit = scale * best_t;
 
-  uint32_t cur = sc.root_ref;
+  uint32_t cur = mv.root_ref;
   if (!(cur & kLeafBit)) {
     float tn, tf;
     if (kCount) ++tally.boxes;
-    if (!box_pass_inner(ld3(sc.root_min), ld3(sc.root_max), oo, od, inv, exact_only, tn, tf)) return;
-    if (exact_only) slab_cull(ld3(sc.root_min), ld3(sc.root_max), oo, inv, tn, tf);
+    if (!box_pass_inner(ld3(mv.root_min), ld3(mv.root_max), oo, od, inv, exact_only, tn, tf)) return;
+    if (exact_only) slab_cull(ld3(mv.root_min), ld3(mv.root_max), oo, inv, tn, tf);
     if (box_culled(tn, tf, limit)) return;
   }
   const float4* tris = sc.tris + kTriVec4 * (size_t)tri_base;
@@ -409,8 +409,8 @@ __device__ __forceinline__ void mesh_closest_wide(const Ray& ray, const DScene& 
       cur = stack[sp * kWave];
       continue;
     }
-    const float4 w0 = sc.wide[4u * (size_t)cur], w1 = sc.wide[4u * (size_t)cur + 1u];
-    const float4 w2 = sc.wide[4u * (size_t)cur + 2u], w3 = sc.wide[4u * (size_t)cur + 3u];
+    const float4 w0 = mv.wide[4u * (size_t)cur], w1 = mv.wide[4u * (size_t)cur + 1u];
+    const float4 w2 = mv.wide[4u * (size_t)cur + 2u], w3 = mv.wide[4u * (size_t)cur + 3u];
     const uint32_t lref = __float_as_uint(w3.x), rref = __float_as_uint(w3.y);
     const f3 lmin = mk3(w0.x, w0.y, w0.z), lmax = mk3(w0.w, w1.x, w1.y);
     const f3 rmin = mk3(w1.z, w1.w, w2.x), rmax = mk3(w2.y, w2.z, w2.w);
@@ -505,7 +505,7 @@ __device__ __forceinline__ bool ray_scene_wide(Ray ray, const DScene& sc, Hit& r
       float t = ray.tmax;
       int k = -1;
       const uint32_t base = sc.object_tri_base[i];
-      mesh_closest_wide<kCount>(ray, sc, obj, base, t, k, stack, flags, tally);
+      mesh_closest_wide<kCount>(ray, sc, sc.mesh_views[sc.object_mesh[i]], obj, base, t, k, stack, flags, tally);
       if (k >= 0) {
         ray.tmax = t;
         rec.t = t;
@@ -1011,7 +1011,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     // everything a winner needs from memory -- its parent's box, its normal -- requested in one go (three
     // dependent round trips otherwise: this code runs every few loop iterations)
     const size_t win = (size_t)max(best_k, 0);
-    const float4 pb0 = sc.leaf_parent[2u * win], pb1 = sc.leaf_parent[2u * win + 1u];
+    const float4 pb0 = sc.cur.leaf_parent[2u * win], pb1 = sc.cur.leaf_parent[2u * win + 1u];
     const float4 tc = tris[kTriVec4 * win + 2u];
     if (best_k >= 0) {
       // world box (ray_aabb, intersections.cuh:87-103): quotients by reciprocal, each within 3 ulp of the quotient
@@ -1169,7 +1169,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           const float carried = ldnt(&hits.tp[slot]).x;
           if (carried >= 0.0f) t_in = carried;
         }
-        bool go = sc.bvh_node_count != 0u;
+        bool go = sc.cur.bvh_node_count != 0u;
         bool wrote = false;
         if (go) {
           // inverse_transform_ray (transform.hpp:51-58) for the walk only: the walk has to be conservative, not
@@ -1190,9 +1190,9 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           // four times that bound (|b| <= the root box) is folded into the two origin terms so the near side
           // can only move nearer and the far side farther.
           const f3 oi = mk3(-(oo_walk.x * inv.x), -(oo_walk.y * inv.y), -(oo_walk.z * inv.z));
-          const float bx = fmaxf(fabsf(sc.root_min[0]), fabsf(sc.root_max[0]));
-          const float by = fmaxf(fabsf(sc.root_min[1]), fabsf(sc.root_max[1]));
-          const float bz = fmaxf(fabsf(sc.root_min[2]), fabsf(sc.root_max[2]));
+          const float bx = fmaxf(fabsf(sc.cur.root_min[0]), fabsf(sc.cur.root_max[0]));
+          const float by = fmaxf(fabsf(sc.cur.root_min[1]), fabsf(sc.cur.root_max[1]));
+          const float bz = fmaxf(fabsf(sc.cur.root_min[2]), fabsf(sc.cur.root_max[2]));
           const f3 tol = mk3(4e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
                              4e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
                              4e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
@@ -1212,7 +1212,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
             best_t = t_in;
             best_k = -1;
             limit = scale * best_t * 1.001f;
-            cur = sc.bvh4_root;
+            cur = sc.cur.bvh4_root;
             sp = sbase = 0;
             ray_boxes = 0u;
             if (split_mode) {  // (only when rays are still handed out after a split: never in practice)
@@ -1272,7 +1272,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       // are requested twice instead; a 64-byte record is simply read whole)
       constexpr bool kLeaf48 = kTriVec4 == 3u;
       const char* rec = is_leaf ? reinterpret_cast<const char*>(tris) + (16u * kTriVec4) * (size_t)index
-                                : reinterpret_cast<const char*>(sc.bvh4q) + 64u * (size_t)index;
+                                : reinterpret_cast<const char*>(sc.cur.bvh4q) + 64u * (size_t)index;
       const char* rec3 = rec + (kLeaf48 && is_leaf ? 32 : 48);
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w0) : "v"(rec));
       asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(w1) : "v"(rec));
@@ -1313,7 +1313,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
                                        __builtin_fmaf(cnz, ax.z, bn.z)), 0.0f);
           const float tf = fminf(fminf(fminf(__builtin_fmaf(cfx, ax.x, bf.x), __builtin_fmaf(cfy, ax.y, bf.y)),
                                        __builtin_fmaf(cfz, ax.z, bf.z)), limit);
-          if (kCount && ref[c] != sc.dummy_ref) { ++tally.boxes; ++ray_boxes; }
+          if (kCount && ref[c] != sc.cur.dummy_ref) { ++tally.boxes; ++ray_boxes; }
           key[c] = tn <= tf ? tn : __builtin_inff();
         }
         // children nearest first: sort the four (key, ref) pairs, 5 compare-exchanges
@@ -1439,7 +1439,7 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
     Tally unused;
     // the object's world box first (path_tracer.cu:84): the persistent kernel tests it only for its winners
     if (ray_aabb(ray.o, ray.d, ld3(obj->bmin), ld3(obj->bmax)))
-      mesh_closest_wide<false>(ray, sc, obj, tri_base, best_t, best_k, sc.slow_stack + threadIdx.x, flags, unused);
+      mesh_closest_wide<false>(ray, sc, sc.cur, obj, tri_base, best_t, best_k, sc.slow_stack + threadIdx.x, flags, unused);
     if (best_k >= 0) {
       const float4 tc = sc.tris[kTriVec4 * ((size_t)tri_base + (uint32_t)best_k) + 2u];
       const f3 outward = mk3(tc.y, tc.z, tc.w);

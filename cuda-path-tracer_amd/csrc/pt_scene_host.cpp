@@ -108,7 +108,7 @@ int make_object(uint32_t type, uint32_t index, const float* m16, const ptc_spher
   const m4 inv = inverse(m);
   std::memset(out, 0, sizeof *out);
   out->type = type;
-  out->index = type == 0u ? index : 0u;
+  out->index = index;  // sphere number, or the mesh of a scene with a mesh table (0 in the reference: one mesh)
   std::memcpy(out->m, &m, sizeof m);
   std::memcpy(out->inv_m, &inv, sizeof inv);
   f3 lo, hi;

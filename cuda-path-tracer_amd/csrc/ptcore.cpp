@@ -61,6 +61,8 @@ struct ptc_ctx {
   bool has_scene = false;
   uint32_t bvh_nodes = 0, bvh_depth = 0, triangles = 0, bvh4_nodes = 0, bvh4_depth = 0;
   ptc_upload_times upload_times{};
+  std::vector<DMeshView> mesh_views;   // host copy of DScene::mesh_views: a traversal launch gets its object's mesh as DScene::cur
+  std::vector<uint32_t> object_mesh;
 
   // frame
   uint32_t width = 0, height = 0;
@@ -281,12 +283,27 @@ int validate_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   if (s->index_count % 3u) return fail(ctx, PTC_ERR_INVALID, "index_count is not a multiple of 3");
   if (s->object_count > 0xffffu) return fail(ctx, PTC_ERR_INVALID, "more than 65535 objects");
   if (s->index_count && (!s->indices || !s->positions)) return fail(ctx, PTC_ERR_INVALID, "mesh arrays missing");
-  for (uint32_t i = 0; i < s->index_count; ++i)
-    if (s->indices[i] >= s->vertex_count) return fail(ctx, PTC_ERR_INVALID, "vertex index out of range");
+  if (!s->meshes) {
+    for (uint32_t i = 0; i < s->index_count; ++i)
+      if (s->indices[i] >= s->vertex_count) return fail(ctx, PTC_ERR_INVALID, "vertex index out of range");
+  } else {
+    if (s->mesh_count > 0xffffu) return fail(ctx, PTC_ERR_INVALID, "more than 65535 meshes");
+    for (uint32_t m = 0; m < s->mesh_count; ++m) {
+      const ptc_mesh_range& r = s->meshes[m];
+      if ((uint64_t)r.first_vertex + r.vertex_count > s->vertex_count || (uint64_t)r.first_index + r.index_count > s->index_count ||
+          r.index_count % 3u)
+        return fail(ctx, PTC_ERR_INVALID, "mesh range outside the vertex / index arrays");
+      if (r.bvh_node_count && (!s->bvh || (uint64_t)r.first_bvh_node + r.bvh_node_count > s->bvh_node_count))
+        return fail(ctx, PTC_ERR_INVALID, "mesh range outside the BVH array");
+      for (uint32_t i = 0; i < r.index_count; ++i)
+        if (s->indices[r.first_index + i] >= r.vertex_count) return fail(ctx, PTC_ERR_INVALID, "vertex index out of range");
+    }
+  }
   for (uint32_t i = 0; i < s->object_count; ++i) {
     const ptc_object& o = s->objects[i];
     if (o.type > 1u) return fail(ctx, PTC_ERR_INVALID, "unknown object type");
     if (o.type == 0u && o.index >= s->sphere_count) return fail(ctx, PTC_ERR_INVALID, "sphere index out of range");
+    if (o.type == 1u && s->meshes && o.index >= s->mesh_count) return fail(ctx, PTC_ERR_INVALID, "mesh index out of range");
     if (s->object_material_indices[i] >= s->material_count) return fail(ctx, PTC_ERR_INVALID, "material index out of range");
   }
   for (uint32_t i = 0; i < s->material_count; ++i)
@@ -504,6 +521,35 @@ int bvh_on_device(ptc_ctx* ctx, const float* positions, uint32_t vertex_count, c
 }
 }  // namespace
 
+namespace {
+
+// one mesh of the scene on its way to the device
+struct MeshWork {
+  // input slice
+  const float* positions = nullptr;
+  uint32_t vertex_count = 0;
+  const uint32_t* indices = nullptr;
+  uint32_t index_count = 0;
+  const ptc_bvh_node* caller_bvh = nullptr;
+  uint32_t caller_nodes = 0;
+  // reference BVH
+  std::vector<ptc_bvh_node> built;   // host copy of a BVH built here (only when something on the host needs it)
+  const ptc_bvh_node* nodes = nullptr;
+  std::vector<uint32_t> level_base;  // first node of every depth + the node count, when the nodes are stored depth by depth
+  float4* dev_packed = nullptr;      // the device builder's output, already in DMeshView::bvh's layout
+  uint32_t node_count = 0, depth = 0;
+  // layouts
+  DMeshView view{};
+  const uint32_t* tri_order_dev = nullptr;  // depth-first rank -> triangle (device layouts)
+  std::vector<uint32_t> tri_order_host;     // ... (host layouts)
+  uint32_t triangles = 0, w4_depth = 0, w4_nodes = 0, w8_depth = 0;
+  Wide8Accel w8;
+  bool has_w8 = false, layouts_on_device = false;
+  ~MeshWork() { if (dev_packed) (void)hipFree(dev_packed); }
+};
+
+}  // namespace
+
 int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
 {
   if (!ctx || !s) return PTC_ERR_INVALID;
@@ -517,54 +563,77 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     into += std::chrono::duration<float, std::milli>(now - t_lap).count();
     t_lap = now;
   };
-  // bottom-level BVH (scene_description.cpp:99-101), unless the caller brought one
-  std::vector<ptc_bvh_node> built;   // host copy of a BVH built here (only when something on the host needs it)
-  std::vector<uint32_t> level_base;  // first node of every depth + the node count, when the nodes are stored depth by depth
-  float4* dev_packed = nullptr;      // the device builder's output, already in DScene::bvh's layout
-  struct Guard {                     // (not leaked by the error returns below)
-    float4*& p;
-    ~Guard() { if (p) (void)hipFree(p); }
-  } guard{dev_packed};
   const bool want_wide8 = ctx->build_wide8 || ctx->trace_variant == 5;
-  const ptc_bvh_node* nodes = s->bvh;
-  uint32_t node_count = s->bvh ? s->bvh_node_count : 0u;
-  uint32_t depth = 0;
-  if (s->index_count == 0u) {
-    nodes = nullptr;
-    node_count = 0u;  // the reference panics on an empty mesh (bvh.cpp:200); here it is a scene without mesh
-  } else if (!nodes) {
-    int rc;
-    if (ctx->bvh_on_device) {
-      const bool host_copy = !ctx->layout_on_device || want_wide8;
-      if (host_copy) built.resize((size_t)s->index_count / 3u * 2u);
-      rc = bvh_on_device(ctx, s->positions, s->vertex_count, s->indices, s->index_count, host_copy ? built.data() : nullptr,
-                         &depth, &dev_packed, &level_base);
-      if (rc < 0) return rc;
-      times.bvh_on_device = 1u;
-      nodes = host_copy ? built.data() : nullptr;
-    } else {
-      built.resize((size_t)s->index_count / 3u * 2u);
-      rc = build_bvh(s->positions, s->vertex_count, s->indices, s->index_count, built.data(), &depth);
-      if (rc < 0) return fail(ctx, rc, "BVH build failed (empty SAH side: coincident centroids?)");
-      nodes = built.data();
-      (void)bvh_depth_of(nodes, (uint32_t)rc, &level_base);
-    }
-    node_count = (uint32_t)rc;
-  } else {
-    if (int rc = validate_bvh(ctx, nodes, node_count, s->index_count)) return rc;
-    depth = bvh_depth_of(nodes, node_count, &level_base);
-  }
-  lap(times.bvh_build_ms);
-  if (s->bvh) times.bvh_build_ms = 0.0f;
-  // depth-first traversal pushes two children per inner node popped: stack need = depth + 1
-  if (node_count && depth + 2u > (uint32_t)kStackDepth)
-    return fail(ctx, PTC_ERR_STACK, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack");
-  // the layouts come from the device when the nodes are stored depth by depth (the reference's breadth-first order:
-  // always, unless the caller brought a tree numbered some other way)
-  const bool layouts_on_device = ctx->layout_on_device && node_count != 0u && !level_base.empty();
-  if (!layouts_on_device && node_count != 0u && !nodes) return fail(ctx, PTC_ERR_INVALID, "internal: no host copy of the BVH");
 
-  // iterations queued or in flight were asked for against the OLD scene: trace them before it goes away
+  // The meshes of the scene.  The reference keeps ONE mesh whatever the scene file says (scene_description.cpp:42,95),
+  // which is what a description without a mesh table means here; with a table (ptc_mesh_range) every mesh object
+  // instantiates the mesh its `index` names.
+  const uint32_t mesh_count = s->meshes ? s->mesh_count : (s->index_count ? 1u : 0u);
+  std::vector<MeshWork> meshes(mesh_count);
+  for (uint32_t m = 0; m < mesh_count; ++m) {
+    MeshWork& w = meshes[m];
+    if (s->meshes) {
+      const ptc_mesh_range& r = s->meshes[m];
+      w.positions = s->positions + 3u * (size_t)r.first_vertex;
+      w.vertex_count = r.vertex_count;
+      w.indices = s->indices + r.first_index;
+      w.index_count = r.index_count;
+      w.caller_bvh = s->bvh && r.bvh_node_count ? s->bvh + r.first_bvh_node : nullptr;
+      w.caller_nodes = w.caller_bvh ? r.bvh_node_count : 0u;
+    } else {
+      w.positions = s->positions;
+      w.vertex_count = s->vertex_count;
+      w.indices = s->indices;
+      w.index_count = s->index_count;
+      w.caller_bvh = s->bvh;
+      w.caller_nodes = s->bvh ? s->bvh_node_count : 0u;
+    }
+  }
+
+  // ---- phase 1: the reference BVH of every mesh (scene_description.cpp:99-101), unless the caller brought it.  The
+  // old scene is still intact: a failure here leaves the context as it was.
+  uint32_t deepest = 0u, total_nodes = 0u, total_triangles = 0u;
+  for (MeshWork& w : meshes) {
+    if (w.index_count == 0u) continue;  // (the reference panics on an empty mesh, bvh.cpp:200; here: a mesh nobody can hit)
+    if (!w.caller_bvh) {
+      int rc;
+      if (ctx->bvh_on_device) {
+        const bool host_copy = !ctx->layout_on_device || want_wide8;
+        if (host_copy) w.built.resize((size_t)w.index_count / 3u * 2u);
+        rc = bvh_on_device(ctx, w.positions, w.vertex_count, w.indices, w.index_count, host_copy ? w.built.data() : nullptr,
+                           &w.depth, &w.dev_packed, &w.level_base);
+        if (rc < 0) return rc;
+        times.bvh_on_device = 1u;
+        w.nodes = host_copy ? w.built.data() : nullptr;
+      } else {
+        w.built.resize((size_t)w.index_count / 3u * 2u);
+        rc = build_bvh(w.positions, w.vertex_count, w.indices, w.index_count, w.built.data(), &w.depth);
+        if (rc < 0) return fail(ctx, rc, "BVH build failed (empty SAH side: coincident centroids?)");
+        w.nodes = w.built.data();
+        (void)bvh_depth_of(w.nodes, (uint32_t)rc, &w.level_base);
+      }
+      w.node_count = (uint32_t)rc;
+      lap(times.bvh_build_ms);
+    } else {
+      w.nodes = w.caller_bvh;
+      w.node_count = w.caller_nodes;
+      if (int rc = validate_bvh(ctx, w.nodes, w.node_count, w.index_count)) return rc;
+      w.depth = bvh_depth_of(w.nodes, w.node_count, &w.level_base);
+      lap(times.copy_ms);
+    }
+    // depth-first traversal pushes two children per inner node popped: stack need = depth + 1
+    if (w.node_count && w.depth + 2u > (uint32_t)kStackDepth)
+      return fail(ctx, PTC_ERR_STACK, "BVH depth " + std::to_string(w.depth) + " exceeds the traversal stack");
+    // the layouts come from the device when the nodes are stored depth by depth (the reference's breadth-first order:
+    // always, unless the caller brought a tree numbered some other way)
+    w.layouts_on_device = ctx->layout_on_device && w.node_count != 0u && !w.level_base.empty();
+    if (!w.layouts_on_device && w.node_count != 0u && !w.nodes) return fail(ctx, PTC_ERR_INVALID, "internal: no host copy of the BVH");
+    deepest = std::max(deepest, w.depth);
+    total_nodes += w.node_count;
+    total_triangles += w.index_count / 3u;
+  }
+
+  // ---- phase 2: the old scene goes.  Iterations queued or in flight were asked for against it: trace them first
   if (int rc = sync_frames(ctx)) return rc;
   free_pool(ctx->scene_allocs);
   ctx->has_scene = false;
@@ -577,140 +646,176 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   const DMaterial* mats = nullptr;
   if (int rc = upload(ctx, ctx->scene_allocs, &mats, reinterpret_cast<const DMaterial*>(s->materials), s->material_count)) return rc;
   d.materials = mats;
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.positions, s->positions, (size_t)s->vertex_count * 3u)) return rc;
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.indices, s->indices, s->index_count)) return rc;
-  if (dev_packed) {
-    ctx->scene_allocs.push_back(dev_packed);
-    d.bvh = dev_packed;
-    dev_packed = nullptr;
-  } else {
-    // node -> two float4: {min.xyz, first}, {max.xyz, count}
-    std::vector<float4> packed((size_t)node_count * 2u);
-    for (uint32_t i = 0; i < node_count; ++i) {
-      const ptc_bvh_node& n = nodes[i];
-      float fbits, cbits;
-      std::memcpy(&fbits, &n.first_child_or_primitive, 4);
-      std::memcpy(&cbits, &n.primitive_count, 4);
-      packed[2u * i] = make_float4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], fbits);
-      packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
-    }
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.bvh, packed.data(), packed.size())) return rc;
-  }
   lap(times.copy_ms);
 
-  // layouts for the fast traversals: wide inner records, the four-wide quantised tree, the triangles of every
-  // instance in depth-first order (+ one all-zero record: the dummy triangle of the four-wide tree's unused slots)
-  const uint32_t mesh_triangles = node_count ? (node_count + 1u) / 2u : 0u;
-  const size_t inst_tris = node_count ? (size_t)mesh_triangles + 1u : 1u;
-  std::vector<uint32_t> tri_base(s->object_count, 0u);
-  size_t mesh_objects = 0;
-  for (uint32_t i = 0; i < s->object_count; ++i)
-    if (s->objects[i].type == 1u) tri_base[i] = (uint32_t)(mesh_objects++ * inst_tris);
-  if (mesh_objects * inst_tris > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
-  uint32_t w4_depth = 0u, w4_nodes = 0u;
-  if (layouts_on_device) {
-    DeviceLayouts lay;
-    const int rc = build_layouts_device(ctx->stream, d.bvh, node_count, level_base, &lay);
-    for (void* q : {(void*)lay.nodes_q, (void*)lay.leaf_parent, (void*)lay.tri_order, (void*)lay.wide})
-      if (q) ctx->scene_allocs.push_back(q);
-    if (rc) return fail(ctx, rc, "traversal layouts failed on the device");
-    d.wide = lay.wide;
-    d.leaf_parent = lay.leaf_parent;
-    d.bvh4q = reinterpret_cast<const uint4*>(lay.nodes_q);
-    d.bvh4_root = lay.root_ref4;
-    d.dummy_ref = lay.dummy_ref;
-    d.root_ref = lay.root_ref2;
-    std::memcpy(d.root_min, lay.root_min, sizeof d.root_min);
-    std::memcpy(d.root_max, lay.root_max, sizeof d.root_max);
-    w4_depth = lay.wide4_depth;
-    w4_nodes = lay.wide4_nodes;
-    lap(times.layout_ms);
+  // ---- phase 3: per mesh, the arrays of the reference layout and the layouts for the fast traversals (wide inner
+  // records, the four-wide quantised tree, the depth-first leaf order)
+  for (MeshWork& w : meshes) {
+    DMeshView& v = w.view;
+    w.triangles = w.node_count ? (w.node_count + 1u) / 2u : 0u;
+    if (int rc = upload(ctx, ctx->scene_allocs, &v.positions, w.positions, (size_t)w.vertex_count * 3u)) return rc;
+    if (int rc = upload(ctx, ctx->scene_allocs, &v.indices, w.indices, w.index_count)) return rc;
+    if (w.dev_packed) {
+      ctx->scene_allocs.push_back(w.dev_packed);
+      v.bvh = w.dev_packed;
+      w.dev_packed = nullptr;
+    } else {
+      // node -> two float4: {min.xyz, first}, {max.xyz, count}
+      std::vector<float4> packed((size_t)w.node_count * 2u);
+      for (uint32_t i = 0; i < w.node_count; ++i) {
+        const ptc_bvh_node& n = w.nodes[i];
+        float fbits, cbits;
+        std::memcpy(&fbits, &n.first_child_or_primitive, 4);
+        std::memcpy(&cbits, &n.primitive_count, 4);
+        packed[2u * i] = make_float4(n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], fbits);
+        packed[2u * i + 1u] = make_float4(n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], cbits);
+      }
+      if (int rc = upload(ctx, ctx->scene_allocs, &v.bvh, packed.data(), packed.size())) return rc;
+    }
+    v.bvh_node_count = w.node_count;
+    lap(times.copy_ms);
+    if (w.layouts_on_device) {
+      DeviceLayouts lay;
+      const int rc = build_layouts_device(ctx->stream, v.bvh, w.node_count, w.level_base, &lay);
+      for (void* q : {(void*)lay.nodes_q, (void*)lay.leaf_parent, (void*)lay.tri_order, (void*)lay.wide})
+        if (q) ctx->scene_allocs.push_back(q);
+      if (rc) return fail(ctx, rc, "traversal layouts failed on the device");
+      v.wide = lay.wide;
+      v.leaf_parent = lay.leaf_parent;
+      v.bvh4q = reinterpret_cast<const uint4*>(lay.nodes_q);
+      v.bvh4_root = lay.root_ref4;
+      v.dummy_ref = lay.dummy_ref;
+      v.root_ref = lay.root_ref2;
+      std::memcpy(v.root_min, lay.root_min, sizeof v.root_min);
+      std::memcpy(v.root_max, lay.root_max, sizeof v.root_max);
+      w.tri_order_dev = lay.tri_order;
+      w.w4_depth = lay.wide4_depth;
+      w.w4_nodes = lay.wide4_nodes;
+      times.layout_on_device = 1u;
+      lap(times.layout_ms);
+    } else {
+      WideAccel wa;
+      if (int rc = build_wide(w.nodes, w.node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
+      Wide4Accel w4;
+      if (int rc = build_wide4(w.nodes, w.node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
+      lap(times.layout_ms);
+      if (int rc = upload(ctx, ctx->scene_allocs, &v.wide, wa.wide.data(), wa.wide.size())) return rc;
+      if (int rc = upload(ctx, ctx->scene_allocs, &v.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
+      {
+        const uint32_t* q = nullptr;
+        if (int rc = upload(ctx, ctx->scene_allocs, &q, w4.nodes_q.data(), w4.nodes_q.size())) return rc;
+        v.bvh4q = reinterpret_cast<const uint4*>(q);
+      }
+      v.bvh4_root = w4.root_ref;
+      v.dummy_ref = w4.dummy_ref;
+      v.root_ref = wa.root_ref;
+      std::memcpy(v.root_min, wa.root_min, sizeof v.root_min);
+      std::memcpy(v.root_max, wa.root_max, sizeof v.root_max);
+      w.tri_order_host = std::move(wa.tri_order);
+      w.w4_depth = w4.depth;
+      w.w4_nodes = w4.node_count;
+      lap(times.copy_ms);
+    }
+    // the eight-wide tree of k_traverse8 (trace variant 5, a cross-check: built on the host, and only when asked for)
+    if (want_wide8 && w.node_count) {
+      if (int rc = build_wide8(w.nodes, w.node_count, w.w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
+      lap(times.layout_ms);
+      const uint32_t* q = nullptr;
+      if (int rc = upload(ctx, ctx->scene_allocs, &q, w.w8.nodes.data(), w.w8.nodes.size())) return rc;
+      v.bvh8 = reinterpret_cast<const uint4*>(q);
+      if (int rc = upload(ctx, ctx->scene_allocs, &v.leaf_parent8, w.w8.leaf_parent.data(), w.w8.leaf_parent.size())) return rc;
+      const size_t records = w.w8.tri_of_record.size();
+      std::vector<uint32_t> record_of_rank(records, 0u);
+      for (size_t k = 0; k < records; ++k) record_of_rank[w.w8.rank_of_record[k]] = (uint32_t)k;
+      if (int rc = upload(ctx, ctx->scene_allocs, &v.record_of_rank8, record_of_rank.data(), record_of_rank.size())) return rc;
+      v.bvh8_depth = w.w8.depth;
+      w.w8_depth = w.w8.depth;
+      w.has_w8 = true;
+      lap(times.copy_ms);
+    }
+  }
+
+  // ---- phase 4: per mesh OBJECT (instance), its world-space triangle records in depth-first order (+ one all-zero
+  // record: the dummy triangle of the four-wide tree's unused slots), and the object -> mesh table
+  std::vector<uint32_t> object_mesh(s->object_count, 0u), tri_base(s->object_count, 0u), base8(s->object_count, 0u);
+  size_t tri_records = 0, tri_records8 = 0;
+  for (uint32_t i = 0; i < s->object_count; ++i) {
+    if (s->objects[i].type != 1u) continue;
+    const uint32_t m = s->meshes ? s->objects[i].index : 0u;
+    object_mesh[i] = m;
+    tri_base[i] = (uint32_t)tri_records;
+    base8[i] = (uint32_t)tri_records8;
+    if (m < mesh_count) {
+      tri_records += (size_t)meshes[m].triangles + 1u;
+      tri_records8 += meshes[m].has_w8 ? meshes[m].w8.tri_of_record.size() : 0u;
+    }
+    if (tri_records > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
+  }
+  {
     float4* tris = nullptr;
-    const size_t tri_vec4 = mesh_objects * inst_tris * kTriVec4;
-    if (int rc2 = dev_alloc(ctx, ctx->scene_allocs, &tris, tri_vec4)) return rc2;
-    if (tri_vec4) HIP_TRY(ctx, hipMemsetAsync(tris, 0, tri_vec4 * sizeof(float4), ctx->stream));
+    if (int rc = dev_alloc(ctx, ctx->scene_allocs, &tris, tri_records * kTriVec4)) return rc;
+    if (tri_records) HIP_TRY(ctx, hipMemsetAsync(tris, 0, tri_records * kTriVec4 * sizeof(float4), ctx->stream));
+    std::vector<float4> host_tris;
     for (uint32_t i = 0; i < s->object_count; ++i) {
-      if (s->objects[i].type != 1u) continue;
+      if (s->objects[i].type != 1u || object_mesh[i] >= mesh_count) continue;
+      const MeshWork& w = meshes[object_mesh[i]];
+      if (w.triangles == 0u) continue;
       m4 m;
       std::memcpy(&m, s->objects[i].m, sizeof m);
-      launch_instance_triangles(ctx->stream, m, d.positions, d.indices, lay.tri_order, mesh_triangles, tris + (size_t)tri_base[i] * kTriVec4);
+      float4* dst = tris + (size_t)tri_base[i] * kTriVec4;
+      if (w.tri_order_dev) {
+        launch_instance_triangles(ctx->stream, m, w.view.positions, w.view.indices, w.tri_order_dev, w.triangles, dst);
+      } else {
+        host_tris.assign((size_t)w.triangles * kTriVec4, make_float4(0.f, 0.f, 0.f, 0.f));
+        build_instance_triangles(m, w.positions, w.indices, w.tri_order_host, host_tris.data());
+        HIP_TRY(ctx, hipMemcpyAsync(dst, host_tris.data(), host_tris.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     d.tris = tris;
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
     lap(times.triangles_ms);
-    times.layout_on_device = 1u;
-  } else {
-    WideAccel wa;
-    if (int rc = build_wide(nodes, node_count, wa)) return fail(ctx, rc, "wide BVH layout failed");
-    Wide4Accel w4;
-    if (int rc = build_wide4(nodes, node_count, w4)) return fail(ctx, rc, "four-wide BVH layout failed");
-    lap(times.layout_ms);
-    std::vector<float4> tris(mesh_objects * inst_tris * kTriVec4);
-    for (uint32_t i = 0; i < s->object_count; ++i) {
-      if (s->objects[i].type != 1u || wa.tri_order.empty()) continue;
-      m4 m;
-      std::memcpy(&m, s->objects[i].m, sizeof m);
-      build_instance_triangles(m, s->positions, s->indices, wa.tri_order, tris.data() + (size_t)tri_base[i] * kTriVec4);
-    }
-    lap(times.triangles_ms);
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.wide, wa.wide.data(), wa.wide.size())) return rc;
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent, w4.leaf_parent.data(), w4.leaf_parent.size())) return rc;
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.tris, tris.data(), tris.size())) return rc;
-    {
-      const uint32_t* q = nullptr;
-      if (int rc = upload(ctx, ctx->scene_allocs, &q, w4.nodes_q.data(), w4.nodes_q.size())) return rc;
-      d.bvh4q = reinterpret_cast<const uint4*>(q);
-    }
-    d.bvh4_root = w4.root_ref;
-    d.dummy_ref = w4.dummy_ref;
-    d.root_ref = wa.root_ref;
-    std::memcpy(d.root_min, wa.root_min, sizeof d.root_min);
-    std::memcpy(d.root_max, wa.root_max, sizeof d.root_max);
-    w4_depth = w4.depth;
-    w4_nodes = w4.node_count;
-    lap(times.copy_ms);
   }
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
-  ctx->layout_counts[0] = (uint64_t)w4_nodes * 64u;                               // bvh4q
-  ctx->layout_counts[1] = node_count ? ((uint64_t)mesh_triangles + 1u) * 32u : 0u;  // leaf_parent
-  ctx->layout_counts[2] = (uint64_t)mesh_objects * inst_tris * 16u * kTriVec4;               // tris
-  ctx->layout_counts[3] = node_count ? ((uint64_t)mesh_triangles - 1u) * 64u : 0u;  // wide
-  ctx->layout_counts[4] = (uint64_t)node_count * 32u;                             // bvh
-  // the eight-wide tree of k_traverse8 (trace variant 5, a cross-check: built on the host, and only when asked for),
-  // its triangle records per instance (own order) and their parent boxes
-  uint32_t w8_depth = 0u;
-  ctx->has_wide8 = false;
-  if (want_wide8 && node_count) {
-    Wide8Accel w8;
-    if (int rc = build_wide8(nodes, node_count, w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
-    lap(times.layout_ms);
-    const uint32_t* q = nullptr;
-    if (int rc = upload(ctx, ctx->scene_allocs, &q, w8.nodes.data(), w8.nodes.size())) return rc;
-    d.bvh8 = reinterpret_cast<const uint4*>(q);
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.leaf_parent8, w8.leaf_parent.data(), w8.leaf_parent.size())) return rc;
-    const size_t records = w8.tri_of_record.size();
-    std::vector<uint32_t> base8(s->object_count, 0u);
-    size_t inst = 0;
-    for (uint32_t i = 0; i < s->object_count; ++i)
-      if (s->objects[i].type == 1u) base8[i] = (uint32_t)(inst++ * records);
-    std::vector<float4> tris8(inst * records * 3u);
+  bool any_w8 = false;
+  if (tri_records8) {
+    std::vector<float4> tris8(tri_records8 * 3u);
     for (uint32_t i = 0; i < s->object_count; ++i) {
-      if (s->objects[i].type != 1u || records == 0u) continue;
+      if (s->objects[i].type != 1u || object_mesh[i] >= mesh_count) continue;
+      const MeshWork& w = meshes[object_mesh[i]];
+      if (!w.has_w8 || w.w8.tri_of_record.empty()) continue;
       m4 m;
       std::memcpy(&m, s->objects[i].m, sizeof m);
-      build_instance_triangles8(m, s->positions, s->indices, w8, tris8.data() + (size_t)base8[i] * 3u);
+      build_instance_triangles8(m, w.positions, w.indices, w.w8, tris8.data() + (size_t)base8[i] * 3u);
     }
     lap(times.triangles_ms);
     if (int rc = upload(ctx, ctx->scene_allocs, &d.tris8, tris8.data(), tris8.size())) return rc;
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base8, base8.data(), base8.size())) return rc;
-    std::vector<uint32_t> record_of_rank(records, 0u);
-    for (size_t k = 0; k < records; ++k) record_of_rank[w8.rank_of_record[k]] = (uint32_t)k;
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.record_of_rank8, record_of_rank.data(), record_of_rank.size())) return rc;
-    lap(times.copy_ms);
-    w8_depth = w8.depth;
-    ctx->has_wide8 = true;
+    any_w8 = true;
   }
-  d.bvh8_depth = w8_depth;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base8, base8.data(), base8.size())) return rc;
+  // every mesh has its eight-wide tree, or variant 5 cannot be chosen
+  ctx->has_wide8 = want_wide8;
+  for (const MeshWork& w : meshes)
+    if (w.node_count && !w.has_w8) ctx->has_wide8 = false;
+  (void)any_w8;
+  ctx->mesh_views.clear();
+  for (const MeshWork& w : meshes) ctx->mesh_views.push_back(w.view);
+  ctx->object_mesh = object_mesh;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.mesh_views, ctx->mesh_views.data(), ctx->mesh_views.size())) return rc;
+  if (int rc = upload(ctx, ctx->scene_allocs, &d.object_mesh, object_mesh.data(), object_mesh.size())) return rc;
+  if (!ctx->mesh_views.empty()) d.cur = ctx->mesh_views[0];
+  lap(times.copy_ms);
+
+  // sizes of mesh 0's arrays (ptc_download_layout)
+  {
+    const MeshWork* w0 = meshes.empty() ? nullptr : &meshes[0];
+    const uint64_t t0 = w0 ? w0->triangles : 0u, n0 = w0 ? w0->node_count : 0u;
+    ctx->layout_counts[0] = (uint64_t)(w0 ? w0->w4_nodes : 0u) * 64u;         // bvh4q
+    ctx->layout_counts[1] = n0 ? (t0 + 1u) * 32u : 0u;                          // leaf_parent
+    ctx->layout_counts[2] = (uint64_t)tri_records * 16u * kTriVec4;            // tris (all instances)
+    ctx->layout_counts[3] = n0 ? (t0 - 1u) * 64u : 0u;                          // wide
+    ctx->layout_counts[4] = n0 * 32u;                                           // bvh
+  }
   d.refill_lanes = ctx->refill_lanes;
   d.split_idle = ctx->split_idle;
   d.static_eighths = ctx->static_eighths;
@@ -721,17 +826,20 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   // goes to this per-thread overflow area (the areas themselves belong to the frame slots, batch_begin)
   d.spill_cap = 0;
   d.lds_cap = ctx->lds_entries;
-  if (node_count) {
+  uint32_t w4_depth = 0u, w4_nodes = 0u;
+  for (const MeshWork& w : meshes) {
+    if (!w.node_count) continue;
     // four-wide walk: up to three refs per level; eight-wide walk: one group per level, 12 of them in LDS
-    const uint32_t need4 = 3u * w4_depth + 2u > d.lds_cap ? 3u * w4_depth + 2u - d.lds_cap : 0u;
+    const uint32_t need4 = 3u * w.w4_depth + 2u > d.lds_cap ? 3u * w.w4_depth + 2u - d.lds_cap : 0u;
     const uint32_t lds8 = std::min<uint32_t>(d.lds_cap, 12u);
-    const uint32_t need8 = ctx->has_wide8 && w8_depth + 2u > lds8 ? w8_depth + 2u - lds8 : 0u;
-    d.spill_cap = std::max(need4, need8);
+    const uint32_t need8 = w.has_w8 && w.w8_depth + 2u > lds8 ? w.w8_depth + 2u - lds8 : 0u;
+    d.spill_cap = std::max(d.spill_cap, std::max(need4, need8));
+    w4_depth = std::max(w4_depth, w.w4_depth);
+    w4_nodes += w.w4_nodes;
   }
   ctx->bvh4_nodes = w4_nodes;
   ctx->bvh4_depth = w4_depth;
   d.object_count = s->object_count;
-  d.bvh_node_count = node_count;
   // launches of the persistent pipeline (TraceLaunch).  A mesh object without nodes (empty mesh) is no launch; the
   // sphere code skips non-sphere objects, so the runs on both sides of it merge.
   ctx->launches.clear();
@@ -741,9 +849,10 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
         if (s->objects[i].type == 0u) return true;
       return false;
     };
+    auto mesh_nodes = [&](uint32_t i) { return object_mesh[i] < mesh_count ? meshes[object_mesh[i]].node_count : 0u; };
     uint32_t run_begin = 0;  // objects [run_begin, i) hold the spheres seen since the last mesh launch
     for (uint32_t i = 0; i < s->object_count; ++i)
-      if (s->objects[i].type == 1u && node_count) {
+      if (s->objects[i].type == 1u && mesh_nodes(i)) {
         const bool any = has_sphere(run_begin, i);
         ctx->launches.push_back({i, any ? run_begin : 0u, any ? i : 0u});
         run_begin = i + 1u;
@@ -754,9 +863,9 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   }
   ctx->scene = d;
   ctx->has_scene = true;
-  ctx->bvh_nodes = node_count;
-  ctx->bvh_depth = depth;
-  ctx->triangles = s->index_count / 3u;
+  ctx->bvh_nodes = total_nodes;
+  ctx->bvh_depth = deepest;
+  ctx->triangles = total_triangles;
   if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, PTC_ERR_HIP, "scene upload failed");
   lap(times.copy_ms);
   times.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -777,7 +886,7 @@ int ptc_download_layout(ptc_ctx* ctx, int which, void* host, uint64_t capacity, 
   if (!ctx || which < 0 || which > 4) return fail(ctx, PTC_ERR_INVALID, "layout: 0 bvh4q, 1 leaf_parent, 2 tris, 3 wide, 4 bvh");
   if (!ctx->has_scene) return fail(ctx, PTC_ERR_NO_SCENE, "no scene uploaded");
   if (int rc = bind_device(ctx)) return rc;
-  const void* src[5] = {ctx->scene.bvh4q, ctx->scene.leaf_parent, ctx->scene.tris, ctx->scene.wide, ctx->scene.bvh};
+  const void* src[5] = {ctx->scene.cur.bvh4q, ctx->scene.cur.leaf_parent, ctx->scene.tris, ctx->scene.cur.wide, ctx->scene.cur.bvh};
   const uint64_t n = ctx->layout_counts[which];
   if (bytes) *bytes = n;
   if (!host) return PTC_OK;
@@ -985,7 +1094,7 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
   if (!ctx || (variant != 0 && variant != 1 && variant != 3 && variant != 5)) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
   if (variant == ctx->trace_variant) return PTC_OK;
-  if (variant == 5 && ctx->has_scene && !ctx->has_wide8 && ctx->scene.bvh_node_count != 0u)
+  if (variant == 5 && ctx->has_scene && !ctx->has_wide8 && ctx->scene.cur.bvh_node_count != 0u)
     return fail(ctx, PTC_ERR_INVALID, "trace variant 5 needs the eight-wide tree: choose it, or set \"build_wide8\", before ptc_upload_scene");
   if (int rc = flush_pending(ctx)) return rc;
   ctx->trace_variant = variant;
@@ -1207,6 +1316,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
       if (int rc = timed_begin(tl)) return rc;
       const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
+      scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
       launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
                       sl.slow_list, sorted ? sl.order : nullptr, ctx->trace_variant, sl.bi);
       wrote = true;
@@ -1826,6 +1936,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
         const auto& l = ctx->launches[k];
         if (l.pre_begin < l.pre_end)
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
+        scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];
         launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr,
                         ctx->trace_variant, bi);
       }

@@ -74,6 +74,7 @@ class FlatScene:
     positions: np.ndarray          # [V,3] float32
     indices: np.ndarray            # [3T] uint32
     bvh: np.ndarray = None         # optional [2T-1] structured, 32 B each
+    mesh_ranges: np.ndarray = None  # optional [M,6] uint32 (ptc_mesh_range): several distinct meshes, objects[i].index = mesh
     keepalive: list = field(default_factory=list)
 
     def to_c(self):
@@ -95,6 +96,11 @@ class FlatScene:
         d.index_count = len(self.indices)
         d.bvh = ptr(self.bvh, _capi.ptc_bvh_node) if self.bvh is not None else None
         d.bvh_node_count = len(self.bvh) if self.bvh is not None else 0
+        if self.mesh_ranges is not None:
+            ranges = np.ascontiguousarray(self.mesh_ranges, dtype=np.uint32).reshape(-1, 6)
+            self.keepalive.append(ranges)
+            d.meshes = ranges.ctypes.data_as(C.POINTER(_capi.ptc_mesh_range))
+            d.mesh_count = len(ranges)
         return d
 
 
@@ -152,7 +158,10 @@ class SceneDescription:
         self.mesh_map_[name] = mesh
         return mesh
 
-    def build_scene(self, prebuilt_bvh=None):  # scene_description.cpp:12-117
+    def build_scene(self, prebuilt_bvh=None, distinct_meshes=False):  # scene_description.cpp:12-117
+        """distinct_meshes=False is the reference: ONE mesh per scene (the first of the mesh map by name), whatever
+        shape a mesh object was added with (scene_description.cpp:42,95).  True: every mesh object instantiates its
+        own mesh (ptc_mesh_range)."""
         lib = _capi.lib()
         names = sorted(self.material_map_, key=lambda s: s.encode())
         index_of = {n: i for i, n in enumerate(names)}
@@ -161,6 +170,11 @@ class SceneDescription:
         mesh = None
         if self.mesh_map_:
             mesh = self.mesh_map_[sorted(self.mesh_map_, key=lambda s: s.encode())[0]]
+        distinct = []   # the meshes of the scene in the order the objects first use them
+        if distinct_meshes:
+            for shape, _ in self.objects_:
+                if not isinstance(shape, Sphere) and not any(shape is m for m in distinct):
+                    distinct.append(shape)
 
         objects = np.zeros(len(self.objects_), dtype=OBJECT_DTYPE)
         spheres = []
@@ -177,10 +191,27 @@ class SceneDescription:
             else:
                 box = np.concatenate([np.asarray(shape.aabb[0], dtype=np.float32),
                                       np.asarray(shape.aabb[1], dtype=np.float32)])
-                _capi.check(lib.ptc_make_object(1, 0, m16.ctypes.data_as(C.POINTER(C.c_float)), None,
+                mesh_index = next(k for k, m in enumerate(distinct) if m is shape) if distinct_meshes else 0
+                _capi.check(lib.ptc_make_object(1, mesh_index, m16.ctypes.data_as(C.POINTER(C.c_float)), None,
                                                 box.ctypes.data_as(C.POINTER(C.c_float)), C.byref(out)))
             objects[i] = np.frombuffer(bytes(out), dtype=OBJECT_DTYPE)[0]
 
+        if distinct_meshes and distinct:
+            if prebuilt_bvh is not None:
+                raise ValueError("prebuilt_bvh describes one mesh; with distinct_meshes the library builds the trees")
+            ranges, v0, i0 = [], 0, 0
+            for m in distinct:
+                ranges.append([v0, len(m.positions), i0, len(m.indices), 0, 0])
+                v0 += len(m.positions)
+                i0 += len(m.indices)
+            return FlatScene(
+                objects=objects,
+                object_material_indices=np.array([index_of[n] for n in self.objects_material_mapping_], dtype=np.uint32),
+                spheres=np.array(spheres, dtype=np.float32).reshape(-1, 4),
+                materials=materials,
+                positions=np.ascontiguousarray(np.concatenate([m.positions for m in distinct]), dtype=np.float32),
+                indices=np.ascontiguousarray(np.concatenate([m.indices for m in distinct]), dtype=np.uint32),
+                mesh_ranges=np.array(ranges, dtype=np.uint32))
         return FlatScene(
             objects=objects,
             object_material_indices=np.array([index_of[n] for n in self.objects_material_mapping_], dtype=np.uint32),

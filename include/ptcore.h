@@ -77,6 +77,16 @@ typedef struct ptc_bvh_node {
   uint32_t primitive_count;
 } ptc_bvh_node;
 
+/* One mesh of a scene that has several (an extension: the reference keeps ONE mesh per scene whatever the scene
+ * file holds, scene_description.cpp:42,95 -- SURVEY section 8 f2).  Ranges into ptc_scene_desc's positions / indices /
+ * bvh arrays; the indices of a mesh count from ITS first vertex, its BVH nodes from ITS first node (each mesh as
+ * bvh_from_mesh would return it on its own). */
+typedef struct ptc_mesh_range {
+  uint32_t first_vertex, vertex_count;
+  uint32_t first_index, index_count;
+  uint32_t first_bvh_node, bvh_node_count; /* bvh_node_count 0: built by ptc_upload_scene */
+} ptc_mesh_range;
+
 /* The flat arrays SceneDescription::build_scene() uploads with six cudaMemcpy calls
  * (scene_description.cpp:54-114).  Host pointers; copied during ptc_upload_scene. */
 typedef struct ptc_scene_desc {
@@ -93,6 +103,10 @@ typedef struct ptc_scene_desc {
   uint32_t index_count;
   const ptc_bvh_node* bvh;                 /* optional: NULL -> built by ptc_upload_scene */
   uint32_t bvh_node_count;
+  /* optional mesh table (NULL: the arrays above are the scene's one mesh, every mesh object instantiates it and
+   * ptc_object::index is ignored, like the reference).  With a table, a mesh object's `index` names its mesh. */
+  const ptc_mesh_range* meshes;
+  uint32_t mesh_count;
 } ptc_scene_desc;
 
 /* Camera, camera.hpp:17-23 */

@@ -142,12 +142,17 @@ def test_make_object_equals_oracle(pkg, orc):
         sp.center[:] = [0.1, -0.2, 0.3]
         sp.radius = 0.75
         box = np.array([-1, -2, -3, 1.5, 2.5, 3.5], dtype=np.float32)
+        # extension (ptc_mesh_range): a mesh object's index names its mesh and is kept
+        got = pkg._capi.ptc_object()
+        assert lib.ptc_make_object(1, 3, m.ctypes.data_as(fp), None, box.ctypes.data_as(fp), C.byref(got)) == 0
+        assert got.index == 3 and got.type == 1
         for typ in (0, 1):
+            index = 4 if typ == 0 else 0   # the reference's mesh objects all carry index 0 (one mesh per scene)
             got = pkg._capi.ptc_object()
-            assert lib.ptc_make_object(typ, 4, m.ctypes.data_as(fp), C.byref(sp) if typ == 0 else None,
+            assert lib.ptc_make_object(typ, index, m.ctypes.data_as(fp), C.byref(sp) if typ == 0 else None,
                                        box.ctypes.data_as(fp) if typ == 1 else None, C.byref(got)) == 0
             want = np.zeros(160, dtype=np.uint8)
-            L.orc_make_object(typ, 4, m.ctypes.data, C.addressof(sp) if typ == 0 else None,
+            L.orc_make_object(typ, index, m.ctypes.data, C.addressof(sp) if typ == 0 else None,
                               box.ctypes.data if typ == 1 else None, want.ctypes.data)
             assert bytes(got) == want.tobytes()
     # the inverse really is one

@@ -1,0 +1,147 @@
+"""Several distinct meshes in one scene (ptc_mesh_range; SURVEY section 8 f2 -- the reference keeps one mesh per scene,
+scene_description.cpp:42,95, so there is no reference behaviour to compare with: parity unpinned).  What is checked:
+a scene of several meshes returns, per ray, the closest hit over its objects in the reference's object order
+(ray_scene_intersection_test, path_tracer.cu:110-128) -- computed from single-object scenes through the tested
+one-mesh path -- and every traversal schedule renders the same image."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pkg, size=(96, 64)):
+    glm = pkg.glmlite
+    sc = pkg.scenes.cornell_spheres(size)            # walls and three small spheres
+    a = pkg.scenes.displaced_sphere_mesh(16, 32)
+    b = pkg.scenes.heightfield_mesh(33, 17, 2.0, 1.0, seed=4)
+    sc.add_mesh("a", a)
+    sc.add_mesh("b", b)
+    sc.add_material("ma", pkg.DiffuseMateral((0.8, 0.3, 0.2)))
+    sc.add_material("mb", pkg.MetalMaterial((0.7, 0.7, 0.9), 0.1))
+    sc.add_object(a, glm.compose([glm.scale(0.5), glm.translate((-0.7, 0.2, 0.4))]), "ma")
+    sc.add_object(b, glm.compose([glm.rotate(np.float32(0.4), (0.0, 1.0, 0.0)), glm.translate((0.2, -0.9, 0.0))]), "mb")
+    sc.add_object(a, glm.compose([glm.rotate(np.float32(0.6), (0.3, 1.0, 0.2)), glm.scale((0.4, 0.25, 0.5)),
+                                  glm.translate((0.8, 0.5, -0.3))]), "mb")
+    return sc, a, b
+
+
+def _frames(pkg, scene, flat, variant, iters=3, mb=6, params=()):
+    w, h = scene.resolution if scene.resolution[0] else (96, 64)
+    with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+        for k, v in params:
+            pt.set_param(k, v)
+        if variant == 5:
+            pt.set_param("build_wide8", 1)
+        pt.create_buffers((96, 64), flat)
+        pt.set_trace_variant(variant)
+        for _ in range(iters):
+            pt.path_trace(scene.camera)
+        return {k: pt.download(k) for k in ("color", "normal", "depth")}, pt.stats()
+
+
+def test_every_schedule_renders_the_same_image(pkg):
+    scene, a, b = _scene(pkg)
+    flat = scene.build_scene(distinct_meshes=True)
+    assert flat.mesh_ranges is not None and len(flat.mesh_ranges) == 2
+    assert [int(o["index"]) for o in flat.objects if o["type"] == 1] == [0, 1, 0]
+    base, base_stats = _frames(pkg, scene, flat, 0)
+    assert base_stats["triangle_count"] == a.triangle_count() + b.triangle_count()
+    for variant, params in ((1, ()), (3, ()), (3, (("frames_in_flight", 6), ("batch_frames", 3))), (5, ()),
+                            (3, (("layout_on_device", 0), ("bvh_build_on_device", 0)))):
+        got, stats = _frames(pkg, scene, flat, variant, params=params)
+        for k in base:
+            assert np.array_equal(got[k], base[k]), (variant, params, k)
+        assert stats["rays_total"] == base_stats["rays_total"]
+    # the two meshes are both seen: the image differs from the reference's one-mesh reading of the same description
+    one, _ = _frames(pkg, scene, scene.build_scene(), 3)
+    assert not np.array_equal(one["color"], base["color"])
+
+
+def test_one_mesh_through_the_table_equals_the_plain_scene(pkg):
+    """a table of one mesh is the reference's scene: same image as without a table"""
+    scene = pkg.scenes.cornell_bunny((96, 64), n_lat=12, n_lon=24)
+    plain = scene.build_scene()
+    table = scene.build_scene(distinct_meshes=True)
+    assert len(table.mesh_ranges) == 1
+    want, _ = _frames(pkg, scene, plain, 3)
+    got, _ = _frames(pkg, scene, table, 3)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_rays_against_single_object_scenes(pkg):
+    """closest hit over the objects in object order == the single-mesh path applied object by object"""
+    glm = pkg.glmlite
+    a = pkg.scenes.displaced_sphere_mesh(16, 32)
+    b = pkg.scenes.heightfield_mesh(33, 17, 2.0, 1.0, seed=4)
+    placements = [(a, glm.compose([glm.scale(0.5), glm.translate((-0.7, 0.2, 0.4))])),
+                  (b, glm.compose([glm.rotate(np.float32(0.4), (0.0, 1.0, 0.0)), glm.translate((0.2, -0.9, 0.0))])),
+                  (a, glm.compose([glm.scale(0.5), glm.translate((-0.55, 0.25, 0.4))])),   # overlaps the first: near ties
+                  (b, glm.compose([glm.rotate(np.float32(0.4), (0.0, 1.0, 0.0)), glm.translate((0.2, -0.9, 0.0))]))]  # coincident: exact ties
+
+    def scene_of(items):
+        sc = pkg.SceneDescription()
+        for k in range(4):
+            sc.add_material(f"m{k}", pkg.DiffuseMateral((0.1 * (k + 1), 0.5, 0.5)))
+        for k, (mesh, tr) in items:
+            sc.add_object(mesh, tr, f"m{k}")
+        return sc
+
+    rng = np.random.default_rng(5)
+    n = 60_000
+    origin = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+    target = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = origin; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.finfo(np.float32).max
+
+    def shoot(flat, variant=3):
+        with pkg.PathTracer() as pt:
+            pt.create_buffers((32, 32), flat)
+            pt.set_trace_variant(variant)
+            return pt.intersect_rays(rays)
+
+    full = scene_of(list(enumerate(placements))).build_scene(distinct_meshes=True)
+    t, nrm, mat, side = shoot(full)
+    # object by object, each alone in a one-mesh scene; a later object wins when its hit is not farther (t <= t_max,
+    # intersections.cuh:80-81)
+    best_t = np.full(n, -1.0, dtype=np.float32)
+    best_n = np.zeros((n, 3), dtype=np.float32); best_m = np.zeros(n, dtype=np.uint32); best_s = np.zeros(n, dtype=np.uint8)
+    for k, item in enumerate(placements):
+        sc = scene_of([(k, item)])
+        sc.add_mesh("only", item[0])
+        tk, nk, mk, sk = shoot(sc.build_scene())
+        take = (tk >= 0) & ((best_t < 0) | (tk <= best_t))
+        best_t[take] = tk[take]; best_n[take] = nk[take]; best_m[take] = mk[take]; best_s[take] = sk[take]
+    hit = best_t >= 0
+    assert 0.2 < hit.mean() < 0.95
+    assert np.array_equal(t >= 0, hit)
+    assert np.array_equal(t[hit], best_t[hit]) and np.array_equal(nrm[hit], best_n[hit])
+    assert np.array_equal(mat[hit], best_m[hit]) and np.array_equal(side[hit], best_s[hit])
+    assert (best_m[hit] == 3).sum() > 100 and (best_m[hit] == 1).sum() == 0   # the coincident copy wins every tie
+    for variant in (0, 1):
+        tv, nv, mv, sv = shoot(full, variant)
+        assert np.array_equal(tv, t) and np.array_equal(nv[hit], nrm[hit]) and np.array_equal(mv[hit], mat[hit])
+
+
+def test_mesh_table_validation(pkg):
+    scene, a, b = _scene(pkg)
+    flat = scene.build_scene(distinct_meshes=True)
+    bad = copy.copy(flat)
+    bad.objects = flat.objects.copy()
+    mesh_rows = [i for i, o in enumerate(bad.objects) if o["type"] == 1]
+    bad.objects["index"][mesh_rows[0]] = 7
+    with pkg.PathTracer() as pt:
+        with pytest.raises(pkg.PtcError) as e:
+            pt.create_buffers((32, 32), bad)
+        assert e.value.code == pkg._capi.PTC_ERR_INVALID and "mesh index" in str(e.value)
+        bad2 = copy.copy(flat)
+        bad2.mesh_ranges = flat.mesh_ranges.copy()
+        bad2.mesh_ranges[1, 1] += 5          # vertex range beyond the array
+        with pytest.raises(pkg.PtcError) as e:
+            pt.create_buffers((32, 32), bad2)
+        assert e.value.code == pkg._capi.PTC_ERR_INVALID
+        pt.create_buffers((32, 32), flat)    # and the context still takes a good scene
