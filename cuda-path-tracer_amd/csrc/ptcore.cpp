@@ -830,7 +830,8 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   for (const MeshWork& w : meshes) {
     if (!w.node_count) continue;
     // four-wide walk: up to three refs per level; eight-wide walk: one group per level, 12 of them in LDS
-    const uint32_t need4 = 3u * w.w4_depth + 2u > d.lds_cap ? 3u * w.w4_depth + 2u - d.lds_cap : 0u;
+    const uint32_t lds4 = std::min<uint32_t>(d.lds_cap, 16u);  // (variant 6 keeps 16 entries in LDS, variant 3 up to 24)
+    const uint32_t need4 = 3u * w.w4_depth + 2u > lds4 ? 3u * w.w4_depth + 2u - lds4 : 0u;
     const uint32_t lds8 = std::min<uint32_t>(d.lds_cap, 12u);
     const uint32_t need8 = w.has_w8 && w.w8_depth + 2u > lds8 ? w.w8_depth + 2u - lds8 : 0u;
     d.spill_cap = std::max(d.spill_cap, std::max(need4, need8));
@@ -1092,7 +1093,12 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  if (!ctx || (variant != 0 && variant != 1 && variant != 3 && variant != 5)) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
+#ifdef PT_WITH_QUEUE_VARIANT
+  const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 5 || variant == 6;  // (6: experiment builds only)
+#else
+  const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 5;
+#endif
+  if (!ctx || !known) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
   if (variant == ctx->trace_variant) return PTC_OK;
   if (variant == 5 && ctx->has_scene && !ctx->has_wide8 && ctx->scene.cur.bvh_node_count != 0u)
     return fail(ctx, PTC_ERR_INVALID, "trace variant 5 needs the eight-wide tree: choose it, or set \"build_wide8\", before ptc_upload_scene");
@@ -1317,8 +1323,10 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       if (int rc = timed_begin(tl)) return rc;
       const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
       scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
+      // (the queue kernel expects an inner node at the root: a one-triangle mesh goes through the plain four-wide kernel)
+      const int kernel = ctx->trace_variant == 6 && (scene.cur.bvh4_root & kLeafBit) ? 3 : ctx->trace_variant;
       launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
-                      sl.slow_list, sorted ? sl.order : nullptr, ctx->trace_variant, sl.bi);
+                      sl.slow_list, sorted ? sl.order : nullptr, kernel, sl.bi);
       wrote = true;
       if (int rc = timed_end(tl)) return rc;
     }
@@ -1938,7 +1946,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
         scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];
         launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr,
-                        ctx->trace_variant, bi);
+                        ctx->trace_variant == 6 && (scene.cur.bvh4_root & kLeafBit) ? 3 : ctx->trace_variant, bi);
       }
       launch_tail_count(ctx->stream, scene, ctx->tail_begin, ctx->tail_end, false, paths, hits, n, 0, chunk_counts, counters, bi);
       e = hipGetLastError();

@@ -1,5 +1,5 @@
 """N streaming frames of a named scene (workload for rocprofv3 runs); prints one JSON line with the ray count.
-usage: run_frames.py <heightfield|bunny|spheres> <frames> [batch_frames] [streams]"""
+usage: run_frames.py <heightfield|bunny|spheres> <frames> [batch_frames] [streams] [trace_variant]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
@@ -7,6 +7,7 @@ pkg = g.load_package()
 which = sys.argv[1]; n = int(sys.argv[2])
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 streams = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else -1
 if which == 'heightfield':
     W, H = 1920, 1080; sc = pkg.scenes.heightfield_scene((W, H))
 elif which == 'bunny':
@@ -19,6 +20,8 @@ if sc.mesh_map_:
 with pkg.PathTracer(max_bounces=8) as pt:
     pt.set_param("frames_in_flight", batch * streams)
     pt.set_param("batch_frames", batch)
+    if variant >= 0:
+        pt.set_trace_variant(variant)
     pt.create_buffers((W, H), flat); pt.max_iterations = 1 << 30
     for _ in range(n):
         pt.path_trace(sc.camera)

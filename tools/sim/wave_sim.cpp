@@ -246,6 +246,68 @@ static void run_wave_stash(size_t begin, size_t end, int tri_min, int cap, int r
   }
 }
 
+// Variant "queue": triangles go to a per-wavefront queue (lane, leaf) and the lane walks on at once; when the queue
+// holds at least `flush` entries (or nothing else is left to do) the whole wavefront tests up to 64 of them in one
+// dense iteration -- any lane tests any entry (the ray comes from the owner's registers), results go back to the owner.
+// A lane whose walk has ended waits until its queued triangles are done.
+struct QEntry { int lane; uint32_t leaf; };
+static void run_wave_queue(size_t begin, size_t end, int flush, int refill, Cost& c)
+{
+  static Lane lanes[64];
+  static int pending[64];
+  std::vector<QEntry> queue;
+  for (int i = 0; i < 64; ++i) { lanes[i].active = false; pending[i] = 0; }
+  size_t next = begin;
+  for (;;) {
+    int idle = 0;
+    for (int i = 0; i < 64; ++i) idle += !lanes[i].active && pending[i] == 0;
+    if (next < end && (idle == 64 || idle >= refill)) {
+      ++c.fetch_runs;
+      for (int i = 0; i < 64; ++i)
+        if (!lanes[i].active && pending[i] == 0 && next < end) {
+          Lane& l = lanes[i];
+          l.ray = (uint32_t)next++;
+          const Ray& r = rays[l.ray];
+          for (int a = 0; a < 3; ++a) l.inv[a] = 1.0f / r.d[a];
+          l.best_t = r.tmax; l.cur = 0; l.sp = 0; l.active = true;
+        }
+    }
+    // leaves on top go to the queue (the lane pops on)
+    for (int i = 0; i < 64; ++i) {
+      Lane& l = lanes[i];
+      while (l.active && nodes[l.cur].count) {
+        queue.push_back({i, l.cur});
+        ++pending[i];
+        if (l.sp) l.cur = l.stack[--l.sp];
+        else l.active = false;
+      }
+    }
+    int n_node = 0;
+    for (int i = 0; i < 64; ++i) n_node += lanes[i].active;
+    if (n_node == 0 && queue.empty()) { if (next >= end) break; continue; }
+    ++c.iters;
+    if ((int)queue.size() >= flush || n_node == 0) {
+      const size_t take = std::min<size_t>(64, queue.size());
+      ++c.tri_runs;
+      c.tri_lanes += take;
+      for (size_t k = 0; k < take; ++k) {
+        const QEntry e = queue[k];
+        Lane& l = lanes[e.lane];
+        float t;
+        if (tri_hit(rays[l.ray], nodes[e.leaf].first / 3, l.best_t, t)) l.best_t = t;
+        --pending[e.lane];
+        ++c.lane_tris;
+      }
+      queue.erase(queue.begin(), queue.begin() + take);
+    } else {
+      ++c.node_runs;
+      c.node_lanes += n_node;
+      for (int i = 0; i < 64; ++i)
+        if (lanes[i].active) { step_node(lanes[i], rays[lanes[i].ray]); ++c.lane_nodes; }
+    }
+  }
+}
+
 int main(int argc, char** argv)
 {
   FILE* f = fopen(argc > 1 ? argv[1] : "/tmp/sim_case.bin", "rb");
@@ -292,6 +354,23 @@ int main(int argc, char** argv)
     const double cost = all.iters * c_head + all.node_runs * c_node + all.tri_runs * c_tri + all.fetch_runs * c_fetch;
     printf("stash tri_min %2d cap %d: iterations/ray*64 %6.2f  node runs %6.2f  tri runs %6.2f  lanes/node run %5.1f  lanes/tri run %5.1f  "
            "nodes/ray %5.2f tris/ray %4.2f  instr/ray %7.1f\n", q.tri_min, q.cap, all.iters / n * 64, all.node_runs / n * 64,
+           all.tri_runs / n * 64, all.node_lanes / std::max(1.0, all.node_runs), all.tri_lanes / std::max(1.0, all.tri_runs),
+           all.lane_nodes / n, all.lane_tris / n, cost / n);
+  }
+  // dense triangle iteration: the test itself (85) + fetching the owner's ray and writing the result back (~35);
+  // node iteration with the enqueue-and-pop-on path (~20 more than today's)
+  const double c_tri_dense = 120, c_node_q = c_node + 20;
+  for (int flush : {16, 24, 32, 48, 64}) {
+    Cost all;
+    size_t at = 0;
+    for (int b = 0; b < 8 && per_bounce[b]; ++b) {
+      for (size_t s = 0; s < per_bounce[b]; s += per_wave) run_wave_queue(at + s, at + std::min<size_t>(per_bounce[b], s + per_wave), flush, refill, all);
+      at += per_bounce[b];
+    }
+    const double n = (double)at;
+    const double cost = all.node_runs * (c_head + c_node_q) + all.tri_runs * (c_head + c_tri_dense) + all.fetch_runs * c_fetch;
+    printf("queue flush %2d: iterations/ray*64 %6.2f  node runs %6.2f  tri runs %6.2f  lanes/node run %5.1f  lanes/tri run %5.1f  "
+           "nodes/ray %5.2f tris/ray %4.2f  instr/ray %7.1f\n", flush, all.iters / n * 64, all.node_runs / n * 64,
            all.tri_runs / n * 64, all.node_lanes / std::max(1.0, all.node_runs), all.tri_lanes / std::max(1.0, all.tri_runs),
            all.lane_nodes / n, all.lane_tris / n, cost / n);
   }
