@@ -2,6 +2,7 @@
 nodes, bit for bit -- same split decisions (pt_bvh_rules.hpp), level order = the reference's breadth-first numbering
 (accelerators/bvh.cpp:228-250)."""
 import copy
+import ctypes as C
 
 import numpy as np
 import pytest
@@ -67,6 +68,20 @@ def test_device_builder_errors(pkg):
         with pytest.raises(pkg.PtcError) as e:   # coincident centroids: the reference panics (bvh.cpp:84-85)
             pt.build_bvh(pkg.Mesh(pos, np.tile(np.array([0, 1, 2], dtype=np.uint32), 6)))
         assert e.value.code == pkg._capi.PTC_ERR_BVH
+        with pytest.raises(pkg.PtcError) as e:   # the same through the many-triangle path (bins by atomics)
+            pt.build_bvh(pkg.Mesh(pos, np.tile(np.array([0, 1, 2], dtype=np.uint32), 100)))
+        assert e.value.code == pkg._capi.PTC_ERR_BVH
+        # ... and deep inside an otherwise fine mesh: 40 coincident triangles among 2000 others
+        soup = _soup(pkg, 2000, 11)
+        dup = np.concatenate([soup.indices, np.tile(soup.indices[:3], 40)])
+        with pytest.raises(pkg.PtcError) as e:
+            pt.build_bvh(pkg.Mesh(soup.positions, dup))
+        assert e.value.code == pkg._capi.PTC_ERR_BVH
+        rc = pkg.lib().ptc_build_bvh(soup.positions.ctypes.data_as(C.POINTER(C.c_float)), len(soup.positions),
+                                     dup.ctypes.data_as(C.POINTER(C.c_uint32)), len(dup),
+                                     np.zeros(2 * (len(dup) // 3), dtype=pkg.scene_description.BVH_NODE_DTYPE).ctypes.data_as(
+                                         C.POINTER(pkg._capi.ptc_bvh_node)), None)
+        assert rc == pkg._capi.PTC_ERR_BVH       # the host builder fails the same way
         with pytest.raises(pkg.PtcError) as e:
             pt.build_bvh(pkg.Mesh(pos, np.array([0, 1, 7], dtype=np.uint32)))
         assert e.value.code == pkg._capi.PTC_ERR_INVALID
