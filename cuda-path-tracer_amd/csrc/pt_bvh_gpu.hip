@@ -11,7 +11,7 @@
 // Layout: the triangle ids live in one array of T positions; a node owns a contiguous range [start, start + count).
 // Per level:
 //   k_centroid_bounds   nodes of more than 32: bounds of the centroids (order-preserving integer min/max atomics,
-//                       one set per wavefront where a wavefront lies inside one node: the top levels)
+//                       one set per workgroup of 1024 positions / per wavefront where these lie inside one node)
 //   k_bins              nodes of more than 32: each triangle's SAH bucket; per bucket count and box (LDS bins when a
 //                       workgroup lies inside one node, global atomics otherwise: contention only exists at the top)
 //   k_split_nodes       one thread per node: leaf record, or axis / split and the two child ranges (rank among the
