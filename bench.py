@@ -412,6 +412,9 @@ def run_config2(args, pkg, torch, local_rank):
     pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
     pt.set_param("frames_in_flight", streams * batch)
     pt.set_param("batch_frames", batch)
+    for kv in args.param:
+        name, value = kv.split("=")
+        pt.set_param(name, int(value))
     pt.create_buffers((W, H), flat)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     pt.max_iterations = 1 << 30
@@ -481,6 +484,9 @@ def run_config5(args, pkg, torch, local_rank):
         pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
         pt.set_param("frames_in_flight", 4)   # a present after every iteration leaves no room for more
         pt.set_param("batch_frames", 2)
+        for kv in args.param:
+            name, value = kv.split("=")
+            pt.set_param(name, int(value))
         pt.create_buffers((W, H), flat)
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
         pt.max_iterations = 1 << 30

@@ -267,6 +267,10 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
 // first: nothing has written the hit records in this bounce yet
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi);
+// a run [obj_begin, obj_end) of mesh objects of the SAME mesh in one launch (k_traverse4m): variant 3 only
+void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
+                         DHits hits, int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
+                         uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                      uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi);

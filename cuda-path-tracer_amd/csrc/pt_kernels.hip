@@ -1484,6 +1484,7 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 }
 
 #include "pt_traverse8.inc"
+#include "pt_traverse4m.inc"
 // An experiment that is kept as source, not in the default build (dead ends): the four-wide walk
 // with a per-wavefront triangle queue, trace variant 6.  make variant TAG=queue EXTRA=-DPT_WITH_QUEUE_VARIANT=1
 #ifndef PT_WITH_QUEUE_VARIANT
@@ -2183,6 +2184,19 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
 {
   hipLaunchKernelGGL(k_scan, dim3(bi.count), dim3(1024), 0, s, bounce, last_bounce ? 1 : 0, chunk_counts, chunk_offsets,
                      counters, bi);
+}
+void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
+                         DHits hits, int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
+                         uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi)
+{
+  const dim3 grid(waves), block(kWave);
+  if (count_tests) {
+    if (first) hipLaunchKernelGGL((k_traverse4m<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    else hipLaunchKernelGGL((k_traverse4m<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+  } else {
+    if (first) hipLaunchKernelGGL((k_traverse4m<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    else hipLaunchKernelGGL((k_traverse4m<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+  }
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,

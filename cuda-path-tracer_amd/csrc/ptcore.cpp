@@ -166,6 +166,7 @@ struct ptc_ctx {
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
+  bool merge_instances = true;  // "merge_instances": consecutive instances of one mesh walked by one launch (k_traverse4m)
   bool bvh_on_device = true;  // "bvh_build_on_device": the reference BVH of ptc_upload_scene from pt_bvh_gpu.hip
   bool layout_on_device = true;  // "layout_on_device": the traversal layouts derived from it, too
   bool build_wide8 = false;      // "build_wide8": the eight-wide tree of trace variant 5 (host-built)
@@ -1139,6 +1140,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     (name[0] == 'l' ? ctx->layout_on_device : ctx->build_wide8) = value != 0;
     return PTC_OK;
   }
+  if (std::strcmp(name, "merge_instances") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "merge_instances must be 0 or 1");
+    ctx->merge_instances = value != 0;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "bvh_build_on_device") == 0) {
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "bvh_build_on_device must be 0 or 1");
     ctx->bvh_on_device = value != 0;
@@ -1323,10 +1329,24 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       if (int rc = timed_begin(tl)) return rc;
       const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
       scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
-      // (the queue kernel expects an inner node at the root: a one-triangle mesh goes through the plain four-wide kernel)
-      const int kernel = ctx->trace_variant == 6 && (scene.cur.bvh4_root & kLeafBit) ? 3 : ctx->trace_variant;
-      launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
-                      sl.slow_list, sorted ? sl.order : nullptr, kernel, sl.bi);
+      // a run of objects that instantiate the same mesh, with nothing between them, is walked by ONE launch: a lane
+      // keeps its ray and takes the instances in turn (k_traverse4m; "merge_instances")
+      size_t run = 1;
+      if (ctx->trace_variant == 3 && ctx->merge_instances)
+        while (k + run < ctx->launches.size() && ctx->launches[k + run].pre_begin == ctx->launches[k + run].pre_end &&
+               ctx->launches[k + run].mesh == l.mesh + (uint32_t)run &&
+               ctx->object_mesh[ctx->launches[k + run].mesh] == ctx->object_mesh[l.mesh])
+          ++run;
+      if (run > 1) {
+        launch_traverse_run(sl.stream, scene, l.mesh, l.mesh + (uint32_t)run, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters,
+                            ctx->count_tests, waves, sl.slow_list, sorted ? sl.order : nullptr, sl.bi);
+        k += run - 1;
+      } else {
+        // (the queue kernel expects an inner node at the root: a one-triangle mesh goes through the plain four-wide kernel)
+        const int kernel = ctx->trace_variant == 6 && (scene.cur.bvh4_root & kLeafBit) ? 3 : ctx->trace_variant;
+        launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
+                        sl.slow_list, sorted ? sl.order : nullptr, kernel, sl.bi);
+      }
       wrote = true;
       if (int rc = timed_end(tl)) return rc;
     }

@@ -231,6 +231,8 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      The library asks the HIP runtime for 24 hardware queues (GPU_MAX_HW_QUEUES, default 4:
  *                      streams on one queue serialise) when it is loaded before the runtime starts; an
  *                      application that initialises HIP first should export GPU_MAX_HW_QUEUES=24 itself
+ *   "merge_instances"  1 (default): consecutive mesh objects that instantiate the same mesh are walked by one traversal
+ *                      launch per bounce (a lane keeps its ray and takes the instances in turn); 0: one launch each
  *   "bvh_build_on_device"  1 (default): a scene without BVH gets the reference BVH from the GPU builder
  *                      (ptc_build_bvh_device); 0: from the threaded host builder.  Same nodes either way
  *   "layout_on_device" 1 (default): the traversal layouts (collapsed four-wide tree, leaf order, per-instance

@@ -325,14 +325,18 @@ def test_benchmark_size_soak_across_schedules(pkg, big):
 
 
 def test_config2_size_against_reference_order(pkg):
-    """Config 2: 1280x720, Cornell box + two instances of the 69,984-triangle mesh (one traversal
-    launch per instance and bounce, hits carried between the object segments), 8 bounces, 9 iterations."""
+    """Config 2: 1280x720, Cornell box + two instances of the 69,984-triangle mesh, 8 bounces, 9
+    iterations: both instances walked by one launch per bounce (k_traverse4m, the default), or one launch per
+    instance with the hit carried between them (merge_instances = 0, and the variants that know one object)."""
     scene = pkg.scenes.cornell_bunny((1280, 720))
     flat = scene.build_scene()
     assert len(flat.indices) // 3 == 69_984
     base = frames(pkg, scene, flat, 1280, 720, 9, 8, variant=0, fif=1)
     got = frames(pkg, scene, flat, 1280, 720, 9, 8)
     assert same(got, base)
+    assert same(frames(pkg, scene, flat, 1280, 720, 9, 8, params=(("merge_instances", 0),)), base)
+    # single frames in flight: the tail of every launch runs in work-splitting mode (groups that go on to the next instance)
+    assert same(frames(pkg, scene, flat, 1280, 720, 9, 8, fif=3, params=(("batch_frames", 1), ("split_idle", 1))), base)
     got1 = frames(pkg, scene, flat, 1280, 720, 9, 8, variant=1, fif=4)
     assert same(got1, base)
     assert same(frames(pkg, scene, flat, 1280, 720, 9, 8, variant=5), base)
