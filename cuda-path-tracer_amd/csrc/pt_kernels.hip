@@ -908,9 +908,6 @@ struct BatchFeed {
 #ifndef PT_T4_LDS
 #define PT_T4_LDS 24
 #endif
-#ifndef PT_T4Q_WAVES
-#define PT_T4Q_WAVES 5
-#endif
 #ifndef PT_T4_WAVES
 #define PT_T4_WAVES 5
 #endif
@@ -1485,14 +1482,6 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 
 #include "pt_traverse8.inc"
 #include "pt_traverse4m.inc"
-// An experiment that is kept as source, not in the default build (dead ends): the four-wide walk
-// with a per-wavefront triangle queue, trace variant 6.  make variant TAG=queue EXTRA=-DPT_WITH_QUEUE_VARIANT=1
-#ifndef PT_WITH_QUEUE_VARIANT
-#define PT_WITH_QUEUE_VARIANT 0
-#endif
-#if PT_WITH_QUEUE_VARIANT
-#include "pt_traverse4q.inc"
-#endif
 
 // A run of sphere objects that does not end the object list (the spheres in front of a mesh), continuing from /
 // handing on the closest hit in the hit record.  (The run that ENDS the list -- or is the whole list -- is part of
@@ -2203,18 +2192,6 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
                      uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi)
 {
   const dim3 grid(waves), block(kWave);
-#if PT_WITH_QUEUE_VARIANT
-  if (variant == 6) {  // four-wide tree, triangles through the wavefront's queue
-    if (count_tests) {
-      if (first) hipLaunchKernelGGL((k_traverse4q<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-      else hipLaunchKernelGGL((k_traverse4q<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-    } else {
-      if (first) hipLaunchKernelGGL((k_traverse4q<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-      else hipLaunchKernelGGL((k_traverse4q<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-    }
-    return;
-  }
-#endif
   if (variant == 5) {  // eight-wide tree (reads its rays in slot order: no pick-up order)
     if (count_tests) {
       if (first) hipLaunchKernelGGL((k_traverse8<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);

@@ -1094,11 +1094,7 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-#ifdef PT_WITH_QUEUE_VARIANT
-  const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 5 || variant == 6;  // (6: experiment builds only)
-#else
   const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 5;
-#endif
   if (!ctx || !known) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
   if (variant == ctx->trace_variant) return PTC_OK;
   if (variant == 5 && ctx->has_scene && !ctx->has_wide8 && ctx->scene.cur.bvh_node_count != 0u)
@@ -1342,8 +1338,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
                             ctx->count_tests, waves, sl.slow_list, sorted ? sl.order : nullptr, sl.bi);
         k += run - 1;
       } else {
-        // (the queue kernel expects an inner node at the root: a one-triangle mesh goes through the plain four-wide kernel)
-        const int kernel = ctx->trace_variant == 6 && (scene.cur.bvh4_root & kLeafBit) ? 3 : ctx->trace_variant;
+        const int kernel = ctx->trace_variant;
         launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
                         sl.slow_list, sorted ? sl.order : nullptr, kernel, sl.bi);
       }
@@ -1966,7 +1961,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
         scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];
         launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr,
-                        ctx->trace_variant == 6 && (scene.cur.bvh4_root & kLeafBit) ? 3 : ctx->trace_variant, bi);
+                        ctx->trace_variant, bi);
       }
       launch_tail_count(ctx->stream, scene, ctx->tail_begin, ctx->tail_end, false, paths, hits, n, 0, chunk_counts, counters, bi);
       e = hipGetLastError();
