@@ -138,6 +138,7 @@ SIGNATURES = {
     "ptc_band_publish": (C.c_int, [_P, C.c_int]),
     "ptc_gather_frame": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "ptc_gather_present_rgba8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "ptc_gather_last_us": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "ptc_synchronize": (C.c_int, [_P]),
     "ptc_get_stats": (C.c_int, [_P, C.POINTER(ptc_stats)]),
     "ptc_set_profiling": (C.c_int, [_P, C.c_int, C.c_int]),

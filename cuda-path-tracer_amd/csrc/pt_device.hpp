@@ -16,7 +16,18 @@ constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kChunk = 64;           // paths per compaction chunk = one wavefront
 constexpr int kStackDepth = 64;      // traversal stack entries per ray (LDS, [depth][lane])
 constexpr int kMaxBounces = 64;      // == PTC_MAX_BOUNCES_CAP
-constexpr int kWorkSlots = 128;      // persistent traversal launches per frame that get their own fetch cursors
+// Ray-fetch cursor sets of the persistent traversal launches.  k_raygen zeroes them at the start of a frame and the
+// last wavefront of every traversal launch zeroes the set it used (launch_epilogue), so launch n of a slot's stream
+// takes set n % kWorkSlots whatever the number of launches per frame (objects x bounces is unbounded).
+constexpr int kWorkSlots = 4;
+// Traversal stack entries per lane the four-wide walk keeps in LDS (6 KiB per wavefront at 24); deeper entries go to
+// DScene::spill.  ONE constant for the kernels' LDS arrays and the host's DScene::lds_cap / spill sizing: a build with
+// -DPT_T4_LDS=16 against a host that assumed 24 wrote past its stack (round-2 A/B fault).
+#ifndef PT_T4_LDS
+#define PT_T4_LDS 24
+#endif
+constexpr int kLds4 = PT_T4_LDS;
+static_assert(kLds4 >= 4 && kLds4 <= kStackDepth, "PT_T4_LDS out of range");
 
 // error bits in DeviceCounters::flags
 constexpr uint32_t kFlagStackOverflow = 1u;
@@ -62,23 +73,12 @@ static_assert(sizeof(DMaterial) == 20, "material layout");
 //         Why it suffices for exactness: boxes nest exactly (parent = componentwise min/max of children) and
 //         IEEE subtraction/division are monotonic, so whenever a node passes the reference's box test all its
 //         ancestors pass too; a triangle is reachable in the reference iff its parent's box passes.
-//   bvh8: the same tree collapsed to EIGHT children per node, 80 bytes (20 dwords, five 16-byte loads) per node,
-//         breadth-first (pt_wide8.cpp): dwords 0-2 grid origin xyz; dword 3 = exponent bytes of the three power-of-two
-//         grid steps | imask << 24; dword 4 = child_base, dword 5 = tri_base, dword 6 = lmask; dwords 7-12 lower planes
-//         (lo_x[8] lo_y[8] lo_z[8], child slot s in byte s), dwords 13-18 upper planes; dword 19 unused.  Slot s holds an
-//         inner node iff imask bit s (node index child_base + popcount(imask below s)), a triangle iff lmask bit s
-//         (record tri_base + popcount(lmask below s)); an unused slot has an inside-out box.  Slots stand for octants
-//         of the node: a ray visits them in ascending (s XOR its direction-sign bits).
-//   tris8: per MESH OBJECT, world-space triangle records in bvh8's record order, three float4 each:
-//           {p0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(depth-first rank), -, -}   (the normal is recomputed for the winner)
-//   leaf_parent8: leaf_parent in that record order.
 // float4s per triangle record of DScene::tris: the 48 bytes described above padded to 64, so that a record never
 // straddles two 64-byte segments of a cache line (measured +2 % rays/s against 48-byte records; 3 = unpadded)
 #ifndef PT_TRI_VEC4
 #define PT_TRI_VEC4 4
 #endif
 constexpr uint32_t kTriVec4 = PT_TRI_VEC4;
-constexpr int kNode8Dwords = 20;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
 
@@ -92,10 +92,6 @@ struct DMeshView {
   const float4* wide;              // 4 float4 per inner node
   const float4* leaf_parent;       // 2 float4 per triangle
   const uint4* bvh4q;              // the four-wide nodes in 64 bytes (Wide4Accel::nodes_q), 4 x uint4 per node
-  const uint4* bvh8;               // the eight-wide nodes in 80 bytes (Wide8Accel::nodes), 5 x uint4 per node
-  const float4* leaf_parent8;      // 2 float4 per triangle record
-  const uint32_t* record_of_rank8; // depth-first rank -> triangle record (work splitting: another lane's candidate)
-  uint32_t bvh8_depth;
   uint32_t bvh4_root;
   uint32_t dummy_ref;              // reference in the unused child slots of a four-wide node (an inside-out box, a triangle no ray hits)
   float root_min[3];               // box of the root (tested before descending, like any inner node)
@@ -114,8 +110,6 @@ struct DScene {
   const uint32_t* object_mesh;     // ... and which one each object instantiates (0 for spheres)
   const float4* tris;              // kTriVec4 float4 per instance triangle
   const uint32_t* object_tri_base; // per object: first triangle of its instance in `tris` (meshes only)
-  const float4* tris8;             // 3 float4 per instance triangle, bvh8's record order
-  const uint32_t* object_tri_base8; // per object: first record of its instance in `tris8`
   uint32_t* slow_stack;            // global traversal stack of the launch's exact redo (redo_slow_rays), [kStackDepth][kWave]
   uint2* spill;                    // traversal stack entries beyond the LDS part, [entry][persistent thread]
   uint32_t spill_stride;           // number of persistent threads
@@ -292,7 +286,17 @@ void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, u
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);
 void launch_pack(hipStream_t s, const float4* buf, uint32_t pix_count, int which, float* dst);
-void launch_scatter_band(hipStream_t s, const float* src, DBand band, uint32_t pix_count, int channels, float* frame);
+// the bands of one multi-GPU gather launch (k_gather_bands): up to kGatherBands sources per launch
+constexpr int kGatherBands = 16;
+struct DGatherBands {
+  struct Src {
+    const float* src;
+    DBand band;
+    uint32_t pix_count;
+  } src[kGatherBands];
+};
+void launch_gather_bands(hipStream_t s, const DGatherBands& bands, uint32_t count, uint32_t max_pix, int channels,
+                         uint32_t frame_pixels, float* frame);
 void launch_preview_packed(hipStream_t s, const float* buf, uint32_t pix_count, int channels, int mode, uint32_t* rgba);
 void launch_denoise_positions(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* nd, float4* pos);
 void launch_denoise_pass(hipStream_t s, const DCamera& cam, uint32_t pix_count, const float4* color, const float4* nd,

@@ -47,19 +47,6 @@ struct Wide4Accel {
 // leaf_rank comes from build_wide (same depth-first leaf order as WideAccel::tri_order)
 int build_wide4(const ptc_bvh_node* nodes, uint32_t count, Wide4Accel& out);
 
-// Eight-wide collapse for k_traverse8 (pt_wide8.cpp; record layout at DScene::bvh8 in pt_device.hpp).
-struct Wide8Accel {
-  std::vector<uint32_t> nodes;           // kNode8Dwords per node, breadth-first, root = node 0
-  std::vector<uint32_t> tri_of_record;   // triangle record -> triangle number of the mesh (records in node order)
-  std::vector<uint32_t> rank_of_record;  // triangle record -> depth-first leaf rank in the reference tree (the tie rule)
-  std::vector<float4> leaf_parent;       // 2 per record: box of the leaf's parent in the reference tree
-  uint32_t depth = 0;                    // levels of eight-wide nodes
-  uint32_t node_count = 0;
-};
-int build_wide8(const ptc_bvh_node* nodes, uint32_t count, Wide8Accel& out);
-// world-space triangle records of one instance in Wide8Accel's record order: {p0, e1, e2, bits(rank)}, 3 float4 each
-void build_instance_triangles8(const m4& m, const float* positions, const uint32_t* indices, const Wide8Accel& w8, float4* out);
-
 // World-space triangles of one instance in depth-first leaf order: 3 float4 per triangle.
 void build_instance_triangles(const m4& m, const float* positions, const uint32_t* indices,
                               const std::vector<uint32_t>& tri_order, float4* out);

@@ -905,9 +905,6 @@ struct BatchFeed {
 // ------------------------------------------------------------------------------------------------
 // Conservative FMA slabs on four children per step, children visited nearest first, optimistic acceptance,
 // one exact test of the winner (finalize below), results written in batches just before a refill.
-#ifndef PT_T4_LDS
-#define PT_T4_LDS 24
-#endif
 #ifndef PT_T4_WAVES
 #define PT_T4_WAVES 5
 #endif
@@ -917,7 +914,20 @@ struct BatchFeed {
 #ifndef PT_FLAT_TRI
 #define PT_FLAT_TRI 1
 #endif
-constexpr int kLds4 = PT_T4_LDS;  // traversal stack entries per lane in LDS (6 KiB per wavefront); deeper: DScene::spill
+
+// End of a persistent traversal launch, run by its LAST wavefront (after the exact redo): the bookkeeping of the next
+// launch on this stream starts from zero -- the redo list, the sign-off counter and the fetch cursors of this launch's
+// set for every frame of the batch (plain stores: the next launch starts after this one has completed).
+__device__ __forceinline__ void launch_epilogue(DeviceCounters* counters, int bounce, int work_slot, uint32_t redone,
+                                                const DBatchInfo& bi)
+{
+  for (uint32_t i = threadIdx.x; i < bi.count * 8u; i += (uint32_t)kWave) counters[i >> 3].work[work_slot][i & 7u][0] = 0u;
+  if (threadIdx.x == 0u) {
+    counters->slow_rays[bounce] += redone;
+    counters->slow_count = 0u;
+    counters->waves_done = 0u;
+  }
+}
 
 // Set a ray aside for the exact redo at the end of the launch (redo_slow_rays).  The entry is written with an
 // agent-scope atomic store: the wavefront that drains the list may run on another XCD (its own L2).
@@ -975,7 +985,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
 
   // entries [0, lds_cap) of a lane's stack live in LDS, the rest in the launch's global overflow area (lds_cap is
   // kLds4 except in tests that want the overflow path exercised by small scenes)
-  const int lds_cap = (int)sc.lds_cap;
+  const int lds_cap = min((int)sc.lds_cap, kLds4);  // (the host sets lds_cap <= kLds4: same header)
   auto push = [&](uint32_t ref) {
     if (sp < lds_cap) stack[sp * kWave] = ref;
     else if (sp < lds_cap + (int)sc.spill_cap) sc.spill[(size_t)(sp - lds_cap) * sc.spill_stride + gid].x = ref;
@@ -1473,14 +1483,9 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   if (prev + 1u != gridDim.x) return;
   const uint32_t count = __hip_atomic_load(&counters->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (count != 0u) redo_slow_rays<kFirst>(sc, obj_index, paths, hits, slow_list, count, counters);
-  if (threadIdx.x == 0u) {
-    counters->slow_rays[bounce] += count;
-    counters->slow_count = 0u;
-    counters->waves_done = 0u;
-  }
+  launch_epilogue(counters, bounce, work_slot, count, bi);
 }
 
-#include "pt_traverse8.inc"
 #include "pt_traverse4m.inc"
 
 // A run of sphere objects that does not end the object list (the spheres in front of a mesh), continuing from /
@@ -1850,13 +1855,19 @@ __global__ __launch_bounds__(256) void k_preview(const float4* buf, uint32_t pix
   rgba[i] = to255(c.x) | (to255(c.y) << 8) | (to255(c.z) << 16) | (alpha << 24);
 }
 
-// A rank's packed rows (3 floats per pixel, or 1) into their place in the whole frame (multi-GPU gather on the root)
-__global__ __launch_bounds__(256) void k_scatter_band(const float* src, DBand band, uint32_t pix_count, int channels, float* frame)
+// Multi-GPU gather on the root, ONE launch for all ranks: blockIdx.y = source band.  A band is a rank's packed rows
+// (channels floats per pixel); src is the root's own buffer or a peer's buffer mapped through HIP IPC, read where it
+// lies -- over xGMI when the peer is another GPU, every peer -> root link busy at once, no staging copy.  Thread i of a
+// band moves float i (consecutive threads read consecutive floats; a row of the band is a run of the frame).
+__global__ __launch_bounds__(256) void k_gather_bands(DGatherBands bands, int channels, uint32_t frame_pixels, float* frame)
 {
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= pix_count) return;
-  const size_t pixel = band_pixel(band, s);
-  for (int c = 0; c < channels; ++c) frame[pixel * (size_t)channels + (size_t)c] = src[(size_t)s * (size_t)channels + (size_t)c];
+  const DGatherBands::Src& b = bands.src[blockIdx.y];
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= (uint64_t)b.pix_count * (uint32_t)channels) return;
+  const uint32_t s = (uint32_t)(i / (uint32_t)channels), c = (uint32_t)(i % (uint32_t)channels);
+  const uint32_t pixel = band_pixel(b.band, s);
+  if (pixel >= frame_pixels) return;  // (ptc_band_import has checked the geometry; a stray handle must not write outside)
+  frame[(size_t)pixel * (size_t)channels + c] = __builtin_nontemporal_load(&b.src[i]);
 }
 
 // preview_kernel / preview_depth_kernel on a packed frame (the gathered frame of a multi-GPU run)
@@ -2192,16 +2203,6 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
                      uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi)
 {
   const dim3 grid(waves), block(kWave);
-  if (variant == 5) {  // eight-wide tree (reads its rays in slot order: no pick-up order)
-    if (count_tests) {
-      if (first) hipLaunchKernelGGL((k_traverse8<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-      else hipLaunchKernelGGL((k_traverse8<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-    } else {
-      if (first) hipLaunchKernelGGL((k_traverse8<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-      else hipLaunchKernelGGL((k_traverse8<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, bi);
-    }
-    return;
-  }
   if (count_tests) {
     if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
     else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
@@ -2237,9 +2238,12 @@ void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mo
 {
   hipLaunchKernelGGL(k_preview, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, buf, pix_count, mode, rgba);
 }
-void launch_scatter_band(hipStream_t s, const float* src, DBand band, uint32_t pix_count, int channels, float* frame)
+void launch_gather_bands(hipStream_t s, const DGatherBands& bands, uint32_t count, uint32_t max_pix, int channels,
+                         uint32_t frame_pixels, float* frame)
 {
-  hipLaunchKernelGGL(k_scatter_band, dim3(div_up(pix_count, 256u)), dim3(256), 0, s, src, band, pix_count, channels, frame);
+  const uint64_t floats = (uint64_t)max_pix * (uint32_t)channels;
+  hipLaunchKernelGGL(k_gather_bands, dim3((uint32_t)((floats + 255u) / 256u), count), dim3(256), 0, s, bands, channels,
+                     frame_pixels, frame);
 }
 void launch_preview_packed(hipStream_t s, const float* buf, uint32_t pix_count, int channels, int mode, uint32_t* rgba)
 {

@@ -135,15 +135,15 @@ struct ptc_ctx {
   // several GPUs (ptc_band_*): this rank's exported band buffer, and on the root the peers' mapped buffers
   float* band_buf = nullptr;                // 3 floats per pixel of pix_capacity
   struct Peer {
-    void* mapped = nullptr;                 // hipIpcOpenMemHandle (foreign process) -- or the pointer itself (same process)
+    void* mapped = nullptr;                 // hipIpcOpenMemHandle of the peer process's band buffer
     bool opened = false;
     ptc_band_handle h{};
   };
   std::vector<Peer> peers;                  // by rank
-  float* gather_stage = nullptr;            // root: a peer's band, copied over before it is scattered into rows
   float* gather_frame = nullptr;            // root: the whole frame, 3 floats per pixel
   uint32_t* gather_rgba = nullptr;
-  size_t gather_stage_px = 0;
+  hipEvent_t gather_ev[2] = {nullptr, nullptr};  // around the most recent gather launch (ptc_gather_last_us)
+  bool gather_timed = false;
 
   int iteration = 0;
   int max_iterations = 1;
@@ -169,8 +169,6 @@ struct ptc_ctx {
   bool merge_instances = true;  // "merge_instances": consecutive instances of one mesh walked by one launch (k_traverse4m)
   bool bvh_on_device = true;  // "bvh_build_on_device": the reference BVH of ptc_upload_scene from pt_bvh_gpu.hip
   bool layout_on_device = true;  // "layout_on_device": the traversal layouts derived from it, too
-  bool build_wide8 = false;      // "build_wide8": the eight-wide tree of trace variant 5 (host-built)
-  bool has_wide8 = false;
   uint64_t layout_counts[5] = {0, 0, 0, 0, 0};  // bytes of bvh4q, leaf_parent, tris, wide, bvh (ptc_download_layout)
   uint32_t split_idle = 8;    // "split_idle"
   uint32_t min_waves = 1024;  // "min_waves": fewest persistent wavefronts of a traversal launch
@@ -180,7 +178,7 @@ struct ptc_ctx {
   bool est_valid = false;
   int ray_sort = 0;           // "ray_sort": 1 = traversal lanes pick their rays up grouped by direction octant (bounces >= 1)
   int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2
-  uint32_t lds_entries = 24;  // == kLds4 in pt_kernels.hip (PT_T4_LDS); fewer only through "debug_lds_entries"
+  uint32_t lds_entries = kLds4;  // the kernels' LDS stack (pt_device.hpp); fewer only through "debug_lds_entries"
   int force_slow = 0;
 
   // measurement
@@ -470,9 +468,10 @@ void ptc_destroy(ptc_ctx* ctx)
   if (ctx->xstream_event) (void)hipEventDestroy(ctx->xstream_event);
   for (auto& peer : ctx->peers)
     if (peer.opened && peer.mapped) (void)hipIpcCloseMemHandle(peer.mapped);
-  for (void* q : {(void*)ctx->band_buf, (void*)ctx->gather_stage, (void*)ctx->gather_frame, (void*)ctx->gather_rgba,
-                  (void*)ctx->slot_offset_dev})
+  for (void* q : {(void*)ctx->band_buf, (void*)ctx->gather_frame, (void*)ctx->gather_rgba, (void*)ctx->slot_offset_dev})
     if (q) (void)hipFree(q);
+  for (hipEvent_t e : ctx->gather_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->misc_counters) (void)hipFree(ctx->misc_counters);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -543,9 +542,8 @@ struct MeshWork {
   DMeshView view{};
   const uint32_t* tri_order_dev = nullptr;  // depth-first rank -> triangle (device layouts)
   std::vector<uint32_t> tri_order_host;     // ... (host layouts)
-  uint32_t triangles = 0, w4_depth = 0, w4_nodes = 0, w8_depth = 0;
-  Wide8Accel w8;
-  bool has_w8 = false, layouts_on_device = false;
+  uint32_t triangles = 0, w4_depth = 0, w4_nodes = 0;
+  bool layouts_on_device = false;
   ~MeshWork() { if (dev_packed) (void)hipFree(dev_packed); }
 };
 
@@ -564,7 +562,6 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     into += std::chrono::duration<float, std::milli>(now - t_lap).count();
     t_lap = now;
   };
-  const bool want_wide8 = ctx->build_wide8 || ctx->trace_variant == 5;
 
   // The meshes of the scene.  The reference keeps ONE mesh whatever the scene file says (scene_description.cpp:42,95),
   // which is what a description without a mesh table means here; with a table (ptc_mesh_range) every mesh object
@@ -599,7 +596,7 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     if (!w.caller_bvh) {
       int rc;
       if (ctx->bvh_on_device) {
-        const bool host_copy = !ctx->layout_on_device || want_wide8;
+        const bool host_copy = !ctx->layout_on_device;
         if (host_copy) w.built.resize((size_t)w.index_count / 3u * 2u);
         rc = bvh_on_device(ctx, w.positions, w.vertex_count, w.indices, w.index_count, host_copy ? w.built.data() : nullptr,
                            &w.depth, &w.dev_packed, &w.level_base);
@@ -717,39 +714,18 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
       w.w4_nodes = w4.node_count;
       lap(times.copy_ms);
     }
-    // the eight-wide tree of k_traverse8 (trace variant 5, a cross-check: built on the host, and only when asked for)
-    if (want_wide8 && w.node_count) {
-      if (int rc = build_wide8(w.nodes, w.node_count, w.w8)) return fail(ctx, rc, "eight-wide BVH layout failed");
-      lap(times.layout_ms);
-      const uint32_t* q = nullptr;
-      if (int rc = upload(ctx, ctx->scene_allocs, &q, w.w8.nodes.data(), w.w8.nodes.size())) return rc;
-      v.bvh8 = reinterpret_cast<const uint4*>(q);
-      if (int rc = upload(ctx, ctx->scene_allocs, &v.leaf_parent8, w.w8.leaf_parent.data(), w.w8.leaf_parent.size())) return rc;
-      const size_t records = w.w8.tri_of_record.size();
-      std::vector<uint32_t> record_of_rank(records, 0u);
-      for (size_t k = 0; k < records; ++k) record_of_rank[w.w8.rank_of_record[k]] = (uint32_t)k;
-      if (int rc = upload(ctx, ctx->scene_allocs, &v.record_of_rank8, record_of_rank.data(), record_of_rank.size())) return rc;
-      v.bvh8_depth = w.w8.depth;
-      w.w8_depth = w.w8.depth;
-      w.has_w8 = true;
-      lap(times.copy_ms);
-    }
   }
 
   // ---- phase 4: per mesh OBJECT (instance), its world-space triangle records in depth-first order (+ one all-zero
   // record: the dummy triangle of the four-wide tree's unused slots), and the object -> mesh table
-  std::vector<uint32_t> object_mesh(s->object_count, 0u), tri_base(s->object_count, 0u), base8(s->object_count, 0u);
-  size_t tri_records = 0, tri_records8 = 0;
+  std::vector<uint32_t> object_mesh(s->object_count, 0u), tri_base(s->object_count, 0u);
+  size_t tri_records = 0;
   for (uint32_t i = 0; i < s->object_count; ++i) {
     if (s->objects[i].type != 1u) continue;
     const uint32_t m = s->meshes ? s->objects[i].index : 0u;
     object_mesh[i] = m;
     tri_base[i] = (uint32_t)tri_records;
-    base8[i] = (uint32_t)tri_records8;
-    if (m < mesh_count) {
-      tri_records += (size_t)meshes[m].triangles + 1u;
-      tri_records8 += meshes[m].has_w8 ? meshes[m].w8.tri_of_record.size() : 0u;
-    }
+    if (m < mesh_count) tri_records += (size_t)meshes[m].triangles + 1u;
     if (tri_records > 0x7fffffffull) return fail(ctx, PTC_ERR_OOM, "too many instance triangles");
   }
   {
@@ -778,27 +754,6 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base, tri_base.data(), tri_base.size())) return rc;
     lap(times.triangles_ms);
   }
-  bool any_w8 = false;
-  if (tri_records8) {
-    std::vector<float4> tris8(tri_records8 * 3u);
-    for (uint32_t i = 0; i < s->object_count; ++i) {
-      if (s->objects[i].type != 1u || object_mesh[i] >= mesh_count) continue;
-      const MeshWork& w = meshes[object_mesh[i]];
-      if (!w.has_w8 || w.w8.tri_of_record.empty()) continue;
-      m4 m;
-      std::memcpy(&m, s->objects[i].m, sizeof m);
-      build_instance_triangles8(m, w.positions, w.indices, w.w8, tris8.data() + (size_t)base8[i] * 3u);
-    }
-    lap(times.triangles_ms);
-    if (int rc = upload(ctx, ctx->scene_allocs, &d.tris8, tris8.data(), tris8.size())) return rc;
-    any_w8 = true;
-  }
-  if (int rc = upload(ctx, ctx->scene_allocs, &d.object_tri_base8, base8.data(), base8.size())) return rc;
-  // every mesh has its eight-wide tree, or variant 5 cannot be chosen
-  ctx->has_wide8 = want_wide8;
-  for (const MeshWork& w : meshes)
-    if (w.node_count && !w.has_w8) ctx->has_wide8 = false;
-  (void)any_w8;
   ctx->mesh_views.clear();
   for (const MeshWork& w : meshes) ctx->mesh_views.push_back(w.view);
   ctx->object_mesh = object_mesh;
@@ -826,16 +781,13 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   // stack need of the four-wide walk: up to three entries per level; whatever exceeds the LDS part (24 entries)
   // goes to this per-thread overflow area (the areas themselves belong to the frame slots, batch_begin)
   d.spill_cap = 0;
-  d.lds_cap = ctx->lds_entries;
+  d.lds_cap = std::min<uint32_t>(ctx->lds_entries, (uint32_t)kLds4);
   uint32_t w4_depth = 0u, w4_nodes = 0u;
   for (const MeshWork& w : meshes) {
     if (!w.node_count) continue;
-    // four-wide walk: up to three refs per level; eight-wide walk: one group per level, 12 of them in LDS
-    const uint32_t lds4 = std::min<uint32_t>(d.lds_cap, 16u);  // (variant 6 keeps 16 entries in LDS, variant 3 up to 24)
-    const uint32_t need4 = 3u * w.w4_depth + 2u > lds4 ? 3u * w.w4_depth + 2u - lds4 : 0u;
-    const uint32_t lds8 = std::min<uint32_t>(d.lds_cap, 12u);
-    const uint32_t need8 = w.has_w8 && w.w8_depth + 2u > lds8 ? w.w8_depth + 2u - lds8 : 0u;
-    d.spill_cap = std::max(d.spill_cap, std::max(need4, need8));
+    // four-wide walk: up to three refs per level
+    const uint32_t need4 = 3u * w.w4_depth + 2u > d.lds_cap ? 3u * w.w4_depth + 2u - d.lds_cap : 0u;
+    d.spill_cap = std::max(d.spill_cap, need4);
     w4_depth = std::max(w4_depth, w.w4_depth);
     w4_nodes += w.w4_nodes;
   }
@@ -925,13 +877,13 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   for (auto& peer : ctx->peers)
     if (peer.opened && peer.mapped) (void)hipIpcCloseMemHandle(peer.mapped);
   ctx->peers.clear();
-  for (float** q : {&ctx->band_buf, &ctx->gather_stage, &ctx->gather_frame}) {
+  for (float** q : {&ctx->band_buf, &ctx->gather_frame}) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
   }
   if (ctx->gather_rgba) (void)hipFree(ctx->gather_rgba);
   ctx->gather_rgba = nullptr;
-  ctx->gather_stage_px = 0;
+  ctx->gather_timed = false;
   const size_t P = (size_t)width * height;
   auto& pool = ctx->frame_allocs;
   const size_t chunks = (P + kChunk - 1) / kChunk;
@@ -1094,11 +1046,9 @@ int ptc_set_max_bounces(ptc_ctx* ctx, int max_bounces)
 
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant)
 {
-  const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 5;
-  if (!ctx || !known) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1, 3 or 5)");
+  const bool known = variant == 0 || variant == 1 || variant == 3;
+  if (!ctx || !known) return fail(ctx, PTC_ERR_INVALID, "unknown trace variant (0, 1 or 3)");
   if (variant == ctx->trace_variant) return PTC_OK;
-  if (variant == 5 && ctx->has_scene && !ctx->has_wide8 && ctx->scene.cur.bvh_node_count != 0u)
-    return fail(ctx, PTC_ERR_INVALID, "trace variant 5 needs the eight-wide tree: choose it, or set \"build_wide8\", before ptc_upload_scene");
   if (int rc = flush_pending(ctx)) return rc;
   ctx->trace_variant = variant;
   return PTC_OK;
@@ -1121,7 +1071,7 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     return PTC_OK;
   }
   if (std::strcmp(name, "debug_lds_entries") == 0) {
-    if (value < 1 || value > 24) return fail(ctx, PTC_ERR_INVALID, "debug_lds_entries must be in [1,24]");
+    if (value < 1 || value > kLds4) return fail(ctx, PTC_ERR_INVALID, "debug_lds_entries must be in [1," + std::to_string(kLds4) + "]");
     if (ctx->has_scene) return fail(ctx, PTC_ERR_INVALID, "set debug_lds_entries before ptc_upload_scene");
     ctx->lds_entries = (uint32_t)value;
     return PTC_OK;
@@ -1131,9 +1081,9 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->force_slow = value;
     return PTC_OK;
   }
-  if (std::strcmp(name, "layout_on_device") == 0 || std::strcmp(name, "build_wide8") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, std::string(name) + " must be 0 or 1");
-    (name[0] == 'l' ? ctx->layout_on_device : ctx->build_wide8) = value != 0;
+  if (std::strcmp(name, "layout_on_device") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "layout_on_device must be 0 or 1");
+    ctx->layout_on_device = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "merge_instances") == 0) {
@@ -1183,6 +1133,7 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (std::strcmp(name, "slot_offset") == 0) {
     if (value < 0) return fail(ctx, PTC_ERR_INVALID, "slot_offset must not be negative");
     if (int rc = bind_device(ctx)) return rc;
+    if (int rc = sync_frames(ctx)) return rc;  // frames in flight read the offset when they execute
     ctx->slot_offset = (uint32_t)value;
     HIP_TRY(ctx, hipMemcpy(ctx->slot_offset_dev, &ctx->slot_offset, sizeof(uint32_t), hipMemcpyHostToDevice));
     return PTC_OK;
@@ -1305,7 +1256,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   };
   bool wrote = false;  // some launch of this bounce has written the hit records
   // ray sorting: the shade kernel of the previous bounce has tagged its surviving rays with their direction octant
-  const bool persistent = ctx->trace_variant >= 3;  // 3: four-wide tree, 5: eight-wide tree
+  const bool persistent = ctx->trace_variant == 3;
   const bool sorted = ctx->ray_sort && ctx->trace_variant == 3 && bounce >= 1 && sl.order && !ctx->launches.empty();
   if (sorted) launch_sort_octant(sl.stream, sl.octs, sl.order, ctx->pix_count, bounce, sl.counters, sl.bi);
   if (persistent) {
@@ -1315,11 +1266,6 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       if (l.pre_begin < l.pre_end) {
         launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi);
         wrote = true;
-      }
-      if (sl.work_slot >= kWorkSlots) {  // more traversal launches per frame than cursors: recycle slot 0
-        for (uint32_t fr = 0; fr < sl.bi.count; ++fr)
-          HIP_TRY(ctx, hipMemsetAsync(&sl.counters[fr].work[0][0][0], 0, sizeof(uint32_t) * 8 * 32, sl.stream));
-        sl.work_slot = 0;
       }
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
       if (int rc = timed_begin(tl)) return rc;
@@ -1334,12 +1280,12 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
                ctx->object_mesh[ctx->launches[k + run].mesh] == ctx->object_mesh[l.mesh])
           ++run;
       if (run > 1) {
-        launch_traverse_run(sl.stream, scene, l.mesh, l.mesh + (uint32_t)run, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters,
+        launch_traverse_run(sl.stream, scene, l.mesh, l.mesh + (uint32_t)run, !wrote, in, sl.hits, bounce, sl.work_slot++ % kWorkSlots, sl.counters,
                             ctx->count_tests, waves, sl.slow_list, sorted ? sl.order : nullptr, sl.bi);
         k += run - 1;
       } else {
         const int kernel = ctx->trace_variant;
-        launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++, sl.counters, ctx->count_tests, waves,
+        launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++ % kWorkSlots, sl.counters, ctx->count_tests, waves,
                         sl.slow_list, sorted ? sl.order : nullptr, kernel, sl.bi);
       }
       wrote = true;
@@ -1388,7 +1334,7 @@ int batch_end(ptc_ctx* ctx)
 }
 
 // frames per batch ptc_trace may use right now (only the default traversal kernel reads DBatchInfo)
-int batch_limit(const ptc_ctx* ctx) { return ctx->staged && ctx->trace_variant >= 3 ? ctx->batch : 1; }
+int batch_limit(const ptc_ctx* ctx) { return ctx->staged && ctx->trace_variant == 3 ? ctx->batch : 1; }
 
 // enqueue the iterations ptc_trace has queued
 int flush_pending(ptc_ctx* ctx)
@@ -1667,7 +1613,22 @@ int ptc_band_import(ptc_ctx* root, uint32_t rank, const ptc_band_handle* handle)
   if (!root || !handle || rank > 0xffffu) return PTC_ERR_INVALID;
   if (!root->pix_capacity) return fail(root, PTC_ERR_INVALID, "ptc_resize first");
   if (handle->width != root->width) return fail(root, PTC_ERR_INVALID, "band of another frame width");
-  if ((uint64_t)handle->pix_count > (uint64_t)root->width * root->height) return fail(root, PTC_ERR_INVALID, "band larger than the frame");
+  // The handle arrives from another process: its geometry decides where k_scatter_band writes, so it must describe a
+  // band of THIS frame (a peer that resized or re-partitioned after exporting sends a stale one).
+  {
+    const uint64_t P = (uint64_t)root->width * root->height;
+    if (handle->pix_count == 0u || (uint64_t)handle->pix_count > P) return fail(root, PTC_ERR_INVALID, "band larger than the frame");
+    if (handle->nranks <= 1u) {
+      if ((uint64_t)handle->pix_begin + handle->pix_count > P) return fail(root, PTC_ERR_INVALID, "band reaches beyond the frame");
+    } else {
+      if (handle->block_rows == 0u || handle->rank >= handle->nranks) return fail(root, PTC_ERR_INVALID, "bad interleave in the band handle");
+      uint64_t rows = 0;  // as ptc_set_interleave counts them
+      const uint32_t blocks = (root->height + handle->block_rows - 1u) / handle->block_rows;
+      for (uint32_t gb = handle->rank; gb < blocks; gb += handle->nranks)
+        rows += std::min(handle->block_rows, root->height - gb * handle->block_rows);
+      if (rows * root->width != handle->pix_count) return fail(root, PTC_ERR_INVALID, "band handle does not match this frame's interleave");
+    }
+  }
   if (int rc = bind_device(root)) return rc;
   if (root->peers.size() <= rank) root->peers.resize((size_t)rank + 1u);
   auto& peer = root->peers[rank];
@@ -1697,29 +1658,54 @@ static int gather_rows(ptc_ctx* root, int which, int channels)
   const size_t P = (size_t)root->width * root->height;
   if (!root->gather_frame) HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->gather_frame), P * 3u * sizeof(float)));
   if (!root->band_buf) HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->band_buf), (size_t)root->pix_capacity * 3u * sizeof(float)));
-  // the root's own rows
+  if (!root->gather_ev[0]) {
+    HIP_TRY(root, hipEventCreate(&root->gather_ev[0]));
+    HIP_TRY(root, hipEventCreate(&root->gather_ev[1]));
+  }
+  // the root's own rows, packed like a peer's
   size_t floats = 0;
   if (int rc = band_pack(root, which, root->band_buf, &floats)) return rc;
-  launch_scatter_band(root->stream, root->band_buf, root->band, root->pix_count, channels, root->gather_frame);
-  // every imported rank's rows: one device-to-device copy out of the peer's buffer (xGMI when it lives on another
-  // GPU), then into row order
+  // One launch pulls every band -- the root's own and every imported rank's, straight out of the peers' mapped
+  // buffers -- into row order: all peer -> root xGMI links carry their band at the same time, nothing is staged.
+  HIP_TRY(root, hipEventRecord(root->gather_ev[0], root->stream));
+  DGatherBands bands{};
+  uint32_t n = 0, max_pix = 0;
+  auto flush = [&]() {
+    if (n) launch_gather_bands(root->stream, bands, n, max_pix, channels, (uint32_t)P, root->gather_frame);
+    n = 0;
+    max_pix = 0;
+  };
+  auto add = [&](const float* src, const DBand& band, uint32_t pix_count) {
+    bands.src[n].src = src;
+    bands.src[n].band = band;
+    bands.src[n].pix_count = pix_count;
+    max_pix = std::max(max_pix, pix_count);
+    if (++n == (uint32_t)kGatherBands) flush();
+  };
+  add(root->band_buf, root->band, root->pix_count);
   for (size_t r = 0; r < root->peers.size(); ++r) {
     const auto& peer = root->peers[r];
     if (!peer.mapped) continue;
-    if (peer.h.pix_count > root->gather_stage_px) {
-      HIP_TRY(root, hipStreamSynchronize(root->stream));
-      if (root->gather_stage) HIP_TRY(root, hipFree(root->gather_stage));
-      root->gather_stage = nullptr;
-      root->gather_stage_px = 0;
-      HIP_TRY(root, hipMalloc(reinterpret_cast<void**>(&root->gather_stage), (size_t)peer.h.pix_count * 3u * sizeof(float)));
-      root->gather_stage_px = peer.h.pix_count;
-    }
-    HIP_TRY(root, hipMemcpyAsync(root->gather_stage, peer.mapped, (size_t)peer.h.pix_count * (size_t)channels * sizeof(float),
-                                 hipMemcpyDeviceToDevice, root->stream));
-    const DBand band{peer.h.pix_begin, peer.h.width, peer.h.rank, peer.h.nranks, peer.h.block_rows};
-    launch_scatter_band(root->stream, root->gather_stage, band, peer.h.pix_count, channels, root->gather_frame);
+    add(static_cast<const float*>(peer.mapped), DBand{peer.h.pix_begin, peer.h.width, peer.h.rank, peer.h.nranks, peer.h.block_rows},
+        peer.h.pix_count);
   }
+  flush();
+  HIP_TRY(root, hipEventRecord(root->gather_ev[1], root->stream));
+  root->gather_timed = true;
   return check_last(root, "gather");
+}
+
+int ptc_gather_last_us(ptc_ctx* root, float* microseconds)
+{
+  if (!root || !microseconds) return PTC_ERR_INVALID;
+  *microseconds = 0.0f;
+  if (!root->gather_timed) return fail(root, PTC_ERR_INVALID, "no gather has run");
+  if (int rc = bind_device(root)) return rc;
+  float ms = 0.0f;
+  HIP_TRY(root, hipEventSynchronize(root->gather_ev[1]));
+  HIP_TRY(root, hipEventElapsedTime(&ms, root->gather_ev[0], root->gather_ev[1]));
+  *microseconds = ms * 1e3f;
+  return PTC_OK;
 }
 
 int ptc_gather_frame(ptc_ctx* root, int which, void* dst, int dst_is_device)
@@ -1892,7 +1878,7 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
   // Path rays know two t_min values (1e-4, and 1e-5 after a dielectric: a flag bit) and start every bounce with
   // t_max = FLT_MAX; a caller's t_max enters as the "closest hit so far" the segments carry in the hit record.
   // Rays with another t_min take the one-wavefront-per-64-rays kernel with exact box decisions (variant 1).
-  bool path_like = ctx->trace_variant >= 3;
+  bool path_like = ctx->trace_variant == 3;
   for (uint32_t i = 0; i < n && path_like; ++i) {
     const float tmin = rays[8u * (size_t)i + 3u], tmax = rays[8u * (size_t)i + 7u];
     path_like = (tmin == 1e-4f || tmin == 1e-5f) && tmax >= 0.0f;
@@ -1955,13 +1941,13 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
       bi.count = 1u;
       const uint32_t waves = std::min<uint32_t>(ctx->traverse_waves, std::max<uint32_t>(8u, ((n / (4u * kWave)) + 7u) & ~7u));
       int work_slot = 0;
-      for (size_t k = 0; k < ctx->launches.size() && work_slot < kWorkSlots; ++k) {
+      for (size_t k = 0; k < ctx->launches.size(); ++k) {
         const auto& l = ctx->launches[k];
         if (l.pre_begin < l.pre_end)
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
         scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];
-        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++, counters, false, waves, slow_list, nullptr,
-                        ctx->trace_variant, bi);
+        launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++ % kWorkSlots, counters, false, waves, slow_list,
+                        nullptr, ctx->trace_variant, bi);
       }
       launch_tail_count(ctx->stream, scene, ctx->tail_begin, ctx->tail_end, false, paths, hits, n, 0, chunk_counts, counters, bi);
       e = hipGetLastError();
@@ -2123,101 +2109,6 @@ int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, u
       if (p0.x != p.aabb_min[0] || p0.y != p.aabb_min[1] || p0.z != p.aabb_min[2] || p1.x != p.aabb_max[0] ||
           p1.y != p.aabb_max[1] || p1.z != p.aabb_max[2])
         ++bad;
-    }
-  }
-  // ---- the eight-wide tree of k_traverse8 (pt_wide8.cpp): the same obligations ----
-  {
-    Wide8Accel w8;
-    if (int rc = build_wide8(nodes, node_count, w8)) return rc;
-    const uint32_t n8 = w8.node_count, records = (uint32_t)w8.tri_of_record.size();
-    if (records != triangles || w8.rank_of_record.size() != records || w8.leaf_parent.size() != 2u * (size_t)records) ++bad;
-    std::vector<uint32_t> seen_rank(triangles, 0u), seen_record(records, 0u), seen_node(n8, 0u);
-    for (uint32_t k = 0; k < records && k < w8.rank_of_record.size(); ++k) {
-      const uint32_t r = w8.rank_of_record[k];
-      if (r >= triangles) {
-        ++bad;
-        continue;
-      }
-      ++seen_rank[r];
-      const uint32_t leaf = leaf_of_rank[r];
-      if (w8.tri_of_record[k] != nodes[leaf].first_child_or_primitive / 3u) ++bad;  // the record is that triangle
-      if (parent[leaf] != 0xffffffffu) {
-        const float4 p0 = w8.leaf_parent[2u * (size_t)k], p1 = w8.leaf_parent[2u * (size_t)k + 1u];
-        const ptc_bvh_node& p = nodes[parent[leaf]];
-        if (p0.x != p.aabb_min[0] || p0.y != p.aabb_min[1] || p0.z != p.aabb_min[2] || p1.x != p.aabb_max[0] ||
-            p1.y != p.aabb_max[1] || p1.z != p.aabb_max[2])
-          ++bad;
-      }
-    }
-    for (uint32_t r = 0; r < triangles; ++r)
-      if (seen_rank[r] != 1u) ++bad;
-    // rank range of every eight-wide node (children have larger indices: breadth-first)
-    std::vector<uint32_t> lo8(n8, 0xffffffffu), hi8(n8, 0u), cnt8(n8, 0u);
-    auto popc_below = [](uint32_t mask, int s) { return (uint32_t)__builtin_popcount(mask & ((1u << s) - 1u)); };
-    for (uint32_t n = n8; n-- > 0u;) {
-      const uint32_t* q = &w8.nodes[(size_t)n * kNode8Dwords];
-      const uint32_t imask = q[3] >> 24, lmask = q[6] & 0xffu;
-      if ((imask & lmask) != 0u || (imask | lmask) == 0u) ++bad;
-      for (int sl = 0; sl < 8; ++sl) {
-        if (lmask >> sl & 1u) {
-          const uint32_t k = q[5] + popc_below(lmask, sl);
-          if (k >= records) return PTC_ERR_BVH;
-          ++seen_record[k];
-          lo8[n] = std::min(lo8[n], w8.rank_of_record[k]);
-          hi8[n] = std::max(hi8[n], w8.rank_of_record[k]);
-          cnt8[n] += 1u;
-        } else if (imask >> sl & 1u) {
-          const uint32_t c = q[4] + popc_below(imask, sl);
-          if (c <= n || c >= n8) return PTC_ERR_BVH;
-          ++seen_node[c];
-          lo8[n] = std::min(lo8[n], lo8[c]);
-          hi8[n] = std::max(hi8[n], hi8[c]);
-          cnt8[n] += cnt8[c];
-        }
-      }
-    }
-    for (uint32_t k = 0; k < records; ++k)
-      if (seen_record[k] != 1u) ++bad;
-    for (uint32_t n = 1; n < n8; ++n)
-      if (seen_node[n] != 1u) ++bad;
-    if (n8 == 0u || cnt8[0] != triangles) ++bad;
-    // every quantised child box contains the exact box of the reference node the child stands for
-    for (uint32_t n = 0; n < n8; ++n) {
-      const uint32_t* q = &w8.nodes[(size_t)n * kNode8Dwords];
-      const uint32_t imask = q[3] >> 24, lmask = q[6] & 0xffu;
-      float origin[3];
-      std::memcpy(origin, q, 12);
-      for (int sl = 0; sl < 8; ++sl) {
-        const uint32_t w = (uint32_t)sl >> 2, sh = 8u * ((uint32_t)sl & 3u);
-        if (!((imask | lmask) >> sl & 1u)) {  // unused slot: inside-out on every axis
-          for (int ax = 0; ax < 3; ++ax)
-            if (((q[7 + 2 * ax + w] >> sh) & 0xffu) != 255u || ((q[13 + 2 * ax + w] >> sh) & 0xffu) != 0u) ++bad;
-          continue;
-        }
-        const ptc_bvh_node* x = nullptr;
-        if (lmask >> sl & 1u) {
-          x = &nodes[leaf_of_rank[w8.rank_of_record[q[5] + popc_below(lmask, sl)]]];
-        } else {
-          const uint32_t c = q[4] + popc_below(imask, sl);
-          if (hi8[c] - lo8[c] + 1u != cnt8[c]) {  // the child's leaves are one run of the depth-first order
-            ++bad;
-            continue;
-          }
-          const auto it = node_of_range.find(((uint64_t)lo8[c] << 32) | hi8[c]);
-          if (it == node_of_range.end()) {
-            ++bad;
-            continue;
-          }
-          x = &nodes[it->second];
-        }
-        for (int ax = 0; ax < 3; ++ax) {
-          const double step = std::ldexp(1.0, (int)((q[3] >> (8 * ax)) & 0xffu) - 127);
-          const double lo = (double)origin[ax] + (double)((q[7 + 2 * ax + w] >> sh) & 0xffu) * step;
-          const double hi = (double)origin[ax] + (double)((q[13 + 2 * ax + w] >> sh) & 0xffu) * step;
-          if (lo > (double)x->aabb_min[ax] || hi < (double)x->aabb_max[ax]) ++bad;
-        }
-        ++boxes;
-      }
     }
   }
   if (checked_boxes) *checked_boxes = boxes;

@@ -193,6 +193,12 @@ class PathTracer:
         self._check(self._lib.ptc_gather_frame(self._ctx, sel, out.ctypes.data_as(C.c_void_p), 0))
         return out.reshape(h, w) if ch == 1 else out.reshape(h, w, 3)
 
+    def gather_last_us(self):
+        """root: device time of the most recent gather launch, in microseconds"""
+        us = C.c_float(0.0)
+        self._check(self._lib.ptc_gather_last_us(self._ctx, C.byref(us)))
+        return float(us.value)
+
     def gather_present(self, display_type=DisplayBufferType.final):
         w, h = self._resolution
         out = np.empty((h * w, 4), dtype=np.uint8)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PTC_ABI_VERSION 2
+#define PTC_ABI_VERSION 3
 
 typedef enum ptc_status {
   PTC_OK = 0,
@@ -211,11 +211,6 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
  *                 winning triangle re-checked against its parent's box with the reference's arithmetic
  *                 (sufficient: see DESIGN.md "nesting"); objects walked as sphere / mesh segments; the only
  *                 variant that traces several iterations per launch ("batch_frames")
- *   5           = the same persistent scheme over the tree collapsed to EIGHT children per 80-byte node (children
- *                 in octant slots, visited in the order of the ray's direction signs, one (group, hit mask) stack
- *                 entry per node).  26 % fewer node visits per ray but 45 % more box tests: measured 14 % slower
- *                 than 3 on the benchmark scene; kept as a cross-check and for measurements.
- *                 Its tree is built by ptc_upload_scene only when 5 is selected first or "build_wide8" is set
  *   1           = culled near-first traversal with exact box decisions, one wavefront per 64 fixed paths (the
  *                 walk the default uses for the few rays it sets aside)
  *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no
@@ -238,8 +233,6 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "layout_on_device" 1 (default): the traversal layouts (collapsed four-wide tree, leaf order, per-instance
  *                      triangle records) are derived on the GPU; 0: on the host.  Same bytes either way
  *                      (ptc_download_layout); a caller's BVH that is not numbered depth by depth goes to the host
- *   "build_wide8"      1: ptc_upload_scene also builds the eight-wide tree trace variant 5 walks (host-side; default
- *                      0 unless variant 5 is already selected)
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
@@ -313,8 +306,10 @@ int ptc_download(ptc_ctx* ctx, int which, void* dst, int dst_is_device);
  * traces its rows (ptc_set_interleave / ptc_set_rows) without talking to anyone, and radiance moves only at present
  * time, from every rank straight to the root over xGMI.)
  * The transport is HIP inter-process memory: a rank exports the device buffer that holds its packed rows
- * (ptc_band_export, once), the root maps the peers' buffers (ptc_band_import, once) and pulls them with
- * device-to-device copies whenever a frame is presented (ptc_gather_frame / ptc_gather_present_rgba8).  The handles
+ * (ptc_band_export, once), the root maps the peers' buffers (ptc_band_import, once; the handle's geometry is checked
+ * against the root's frame) and, whenever a frame is presented (ptc_gather_frame / ptc_gather_present_rgba8), ONE
+ * kernel on the root reads every band where it lies -- the peers' over xGMI, all links at once -- and writes it into
+ * row order; nothing is staged.  ptc_gather_last_us reports how long that launch took on the root.  The handles
  * and the "my rows are ready" signal travel over whatever channel the application has between its processes --
  * shared memory in hip_pt --gpus N (host/main.cpp), torch.distributed in bench.py and the tests:
  *     every rank but the root:  ptc_band_publish(ctx, which);   then signal / barrier
@@ -339,6 +334,9 @@ int ptc_gather_frame(ptc_ctx* root, int which, void* dst, int dst_is_device);
  * PTC_DISPLAY_FINAL gathers the accumulated colour (a denoised buffer exists only for a context that owns the whole
  * frame). */
 int ptc_gather_present_rgba8(ptc_ctx* root, void* dst, int dst_is_device, int display_type);
+/* Root: device time of the most recent gather (the root's own pack excluded: from the first to the last band landing
+ * in row order), in microseconds.  Waits for that gather. */
+int ptc_gather_last_us(ptc_ctx* root, float* microseconds);
 
 int ptc_synchronize(ptc_ctx* ctx);                                  /* cudaDeviceSynchronize at cli.cpp:100 */
 int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out);                    /* synchronises */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ptcore.h but not exported by libptcore.so"
     assert set(names) == set(pkg._capi.SIGNATURES), "ctypes binding and header disagree"
-    assert lib.ptc_abi_version() == 2
+    assert lib.ptc_abi_version() == 3
 
 
 def test_struct_layouts_match_reference_sizes(pkg):

@@ -32,8 +32,6 @@ def _frames(pkg, scene, flat, variant, iters=3, mb=6, params=()):
     with pkg.PathTracer(device=0, max_bounces=mb) as pt:
         for k, v in params:
             pt.set_param(k, v)
-        if variant == 5:
-            pt.set_param("build_wide8", 1)
         pt.create_buffers((96, 64), flat)
         pt.set_trace_variant(variant)
         for _ in range(iters):
@@ -48,7 +46,7 @@ def test_every_schedule_renders_the_same_image(pkg):
     assert [int(o["index"]) for o in flat.objects if o["type"] == 1] == [0, 1, 0]
     base, base_stats = _frames(pkg, scene, flat, 0)
     assert base_stats["triangle_count"] == a.triangle_count() + b.triangle_count()
-    for variant, params in ((1, ()), (3, ()), (3, (("frames_in_flight", 6), ("batch_frames", 3))), (5, ()),
+    for variant, params in ((1, ()), (3, ()), (3, (("frames_in_flight", 6), ("batch_frames", 3))),
                             (3, (("layout_on_device", 0), ("bvh_build_on_device", 0)))):
         got, stats = _frames(pkg, scene, flat, variant, params=params)
         for k in base:
@@ -217,3 +215,57 @@ def test_run_of_instances_in_one_launch(pkg):
     hit = best_t >= 0
     assert np.array_equal(t >= 0, hit) and np.array_equal(t[hit], best_t[hit]) and np.array_equal(mat[hit], best_m[hit])
     assert (best_m[hit] == 0).sum() == 0 and (best_m[hit] == 2).sum() > 100   # the coincident later copy wins every tie
+
+
+def test_more_traversal_launches_per_frame_than_cursor_sets(pkg):
+    """Three meshes that cannot share a launch x 50 bounces = 150 traversal launches per frame (the reference's own
+    bounce cap, path_tracer.cu:27).  Round 2 gave each launch of a frame its own fetch-cursor set out of 128 and
+    recycled stale ones beyond that: the dynamic share of the rays was then never walked (advisor finding).  Now a
+    launch's last wavefront zeroes the set it used and launch n takes set n % kWorkSlots, so the count is unbounded.
+    Closed Cornell box: most paths live for all 50 bounces."""
+    scene, a, b = _scene(pkg)
+    flat = scene.build_scene(distinct_meshes=True)
+    base, base_stats = _frames(pkg, scene, flat, 0, iters=2, mb=50)
+    assert base_stats["last_live"][10] > 100   # rays are still alive when the cursor sets have gone round several times
+    for params in ((), (("frames_in_flight", 6), ("batch_frames", 3)), (("merge_instances", 0),),
+                   (("traverse_waves", 8),)):   # 8 wavefronts: no static share, every ray comes from a cursor
+        got, stats = _frames(pkg, scene, flat, 3, iters=2, mb=50, params=params)
+        for k in base:
+            assert np.array_equal(got[k], base[k]), (params, k)
+        assert stats["rays_total"] == base_stats["rays_total"] and stats["last_live"] == base_stats["last_live"], params
+
+
+def test_intersect_rays_with_many_mesh_objects(pkg):
+    """ptc_intersect_rays launches one traversal per mesh object: 150 instances (round 2 stopped silently after 128
+    launches and returned the closest hit over a truncated object list)."""
+    glm = pkg.glmlite
+    mesh = pkg.scenes.displaced_sphere_mesh(6, 12)
+    sc = pkg.SceneDescription()
+    sc.add_mesh("m", mesh)
+    sc.add_material("first", pkg.DiffuseMateral((0.5, 0.5, 0.5)))
+    sc.add_material("last", pkg.DiffuseMateral((0.9, 0.1, 0.1)))
+    count = 150
+    for k in range(count):
+        x, y = (k % 15) - 7.0, (k // 15) - 4.5
+        sc.add_object(mesh, glm.compose([glm.scale(0.35), glm.translate((x, y, 0.0))]), "last" if k >= 128 else "first")
+    sc.add_object(pkg.Sphere((0, 0, 0), 0.2), glm.translate((0.0, 0.0, 2.0)), "first")   # a sphere run behind them all
+    flat = sc.build_scene()
+    rng = np.random.default_rng(11)
+    n = 30_000
+    origin = np.stack([rng.uniform(-8, 8, n), rng.uniform(-5.5, 5.5, n), np.full(n, 6.0)], axis=1).astype(np.float32)
+    d = np.stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), np.full(n, -1.0)], axis=1).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = origin; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.finfo(np.float32).max
+    with pkg.PathTracer() as pt:
+        pt.create_buffers((32, 32), flat)
+        got = pt.intersect_rays(rays)
+        pt.set_trace_variant(0)
+        want = pt.intersect_rays(rays)
+    hit = want[0] >= 0
+    assert 0.2 < hit.mean() < 0.9
+    mats = {name: i for i, name in enumerate(sorted(["first", "last"]))}
+    assert (want[2][hit] == mats["last"]).sum() > 500    # objects beyond the 128th are hit
+    assert np.array_equal(got[0], want[0])
+    for k in (1, 2, 3):
+        assert np.array_equal(got[k][hit], want[k][hit]), k

@@ -51,3 +51,32 @@ def test_cli_with_ranks(pkg, tmp_path):
             bands.append(pt.send_to_preview())
     want = pkg.bands.assemble_interleaved(bands, h, world, 8)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_band_handle_geometry_is_checked_on_import(pkg):
+    """A band handle arrives from another process and decides where the root's gather kernel writes: a stale or
+    corrupt one (the peer resized or re-partitioned after exporting) must be refused before anything is mapped
+    (round-2 advisor finding: only width and pix_count <= W*H were checked)."""
+    import copy
+    capi = pkg._capi
+    scene = pkg.scenes.cornell_spheres((64, 48))
+    flat = scene.build_scene()
+    with pkg.PathTracer() as root, pkg.PathTracer() as peer:
+        root.create_buffers((64, 48), flat)
+        peer.create_buffers((64, 48), flat)
+        peer.set_interleave(1, 2, 8)
+        good = capi.ptc_band_handle.from_buffer_copy(peer.band_export())
+        assert (good.rank, good.nranks, good.block_rows, good.pix_count) == (1, 2, 8, 24 * 64)
+
+        def tampered(**kw):
+            h = copy.copy(good)
+            for k, v in kw.items():
+                setattr(h, k, v)
+            return bytes(h)
+
+        for bad in (dict(block_rows=0), dict(rank=2), dict(rank=5, nranks=3), dict(pix_count=25 * 64),
+                    dict(block_rows=16), dict(nranks=3), dict(width=32), dict(pix_count=0),
+                    dict(nranks=1, pix_begin=64 * 48 - 10), dict(nranks=0, pix_count=64 * 48 + 1)):
+            with pytest.raises(pkg.PtcError) as e:
+                root.band_import(1, tampered(**bad))
+            assert e.value.code == capi.PTC_ERR_INVALID, bad

@@ -18,8 +18,6 @@ def frames(pkg, scene, flat, w, h, iters, mb, variant=None, fif=None, params=())
             pt.set_param("frames_in_flight", fif)
         for k, v in params:
             pt.set_param(k, v)
-        if variant == 5:
-            pt.set_param("build_wide8", 1)   # the eight-wide tree is built only on request
         pt.create_buffers((w, h), flat)
         if variant is not None:
             pt.set_trace_variant(variant)
@@ -56,7 +54,7 @@ def test_every_schedule_matches_reference_order_and_oracle(pkg, orc, small_scene
     base = frames(pkg, scene, flat, w, h, 3, 8, variant=0, fif=1)
     ref = orc.render_streaming(flat, scene.camera, w, h, 0, 3, 8)
     assert np.array_equal(base["color"], ref["color"]) and base["stats"]["rays_total"] == ref["rays"]
-    for variant in (1, 3, 5):
+    for variant in (1, 3):
         for fif in (1, 3):
             got = frames(pkg, scene, flat, w, h, 3, 8, variant=variant, fif=fif)
             assert same(got, base), (variant, fif)
@@ -108,11 +106,10 @@ def test_degenerate_ray_fallback_kernel(pkg, small_scenes):
     flat = scene.build_scene()
     base = frames(pkg, scene, flat, w, h, 2, 6, variant=0, fif=1)
     for mode in (1, 2):   # 1: every ray set aside when fetched; 2: every winner fails its verification
-        for variant in (3, 5):
-            for fif, batch in ((2, 1), (6, 3)):
-                got = frames(pkg, scene, flat, w, h, 2, 6, variant=variant, fif=fif,
-                             params=(("batch_frames", batch), ("debug_force_slow", mode)))
-                assert same(got, base), (mode, variant, fif, batch)
+        for fif, batch in ((2, 1), (6, 3)):
+            got = frames(pkg, scene, flat, w, h, 2, 6, variant=3, fif=fif,
+                         params=(("batch_frames", batch), ("debug_force_slow", mode)))
+            assert same(got, base), (mode, fif, batch)
 
 
 def test_axis_aligned_rays(pkg, orc):
@@ -133,8 +130,7 @@ def test_axis_aligned_rays(pkg, orc):
     ref = orc.render_streaming(flat, s.camera, 65, 65, 0, 2, 6)
     # 65 x 65: the pixel count is not a multiple of 256 (nor of 64) -- the last workgroup of the per-slot kernels is
     # partly beyond the frame, also inside a batch where the next frame's arrays follow directly
-    for variant, fif, params in ((0, 1, ()), (1, 2, ()), (3, 2, ()), (3, 6, (("batch_frames", 3),)), (5, 2, ()),
-                                 (5, 6, (("batch_frames", 3),))):
+    for variant, fif, params in ((0, 1, ()), (1, 2, ()), (3, 2, ()), (3, 6, (("batch_frames", 3),))):
         got = frames(pkg, s, flat, 65, 65, 2, 6, variant=variant, fif=fif, params=params)
         assert np.array_equal(got["color"], ref["color"]) and got["stats"]["rays_total"] == ref["rays"], (variant, fif)
 
@@ -299,10 +295,6 @@ def test_benchmark_size_against_reference_order(pkg, big):
     # walk overflows into the per-slot global area on this tree, concurrently in every launch
     got4 = frames(pkg, scene, flat, 1920, 1080, 10, 8, fif=10, params=(("batch_frames", 1), ("debug_lds_entries", 4)))
     assert same(got4, base)
-    # the eight-wide tree (variant 5), batched and with its group stack spilling
-    assert same(frames(pkg, scene, flat, 1920, 1080, 10, 8, variant=5), base)
-    assert same(frames(pkg, scene, flat, 1920, 1080, 10, 8, variant=5, fif=10,
-                       params=(("batch_frames", 1), ("debug_lds_entries", 3))), base)
     live = got["stats"]["last_live"]
     assert live[0] == 1920 * 1080 and all(a >= b for a, b in zip(live, live[1:]))
     assert np.isfinite(got["color"]).all() and 0.0 <= got["color"].min() and got["color"].max() <= 1.0 + 1e-6
@@ -339,7 +331,6 @@ def test_config2_size_against_reference_order(pkg):
     assert same(frames(pkg, scene, flat, 1280, 720, 9, 8, fif=3, params=(("batch_frames", 1), ("split_idle", 1))), base)
     got1 = frames(pkg, scene, flat, 1280, 720, 9, 8, variant=1, fif=4)
     assert same(got1, base)
-    assert same(frames(pkg, scene, flat, 1280, 720, 9, 8, variant=5), base)
 
 
 def _adversarial_rays(flat, nodes, rng):
@@ -416,9 +407,8 @@ def test_benchmark_size_rays_against_oracle(pkg, orc, big):
     m = hit.astype(bool)
     assert 0.3 < m.mean() < 0.99
     with pkg.PathTracer() as pt:
-        pt.set_param("build_wide8", 1)
         pt.create_buffers((64, 64), flat)
-        for variant in (3, 5, 0, 1):
+        for variant in (3, 0, 1):
             pt.set_trace_variant(variant)
             t, nrm, mat, side = pt.intersect_rays(rays)
             bad = np.nonzero((t >= 0) != m)[0]
@@ -470,9 +460,8 @@ def test_instance_ties_and_carried_hits(pkg, orc):
     # test compared with t_max, path_tracer.cu:93-94, so a few of those may flip: whatever the oracle says)
     assert m[n:n + len(again)].mean() > 0.9
     with pkg.PathTracer() as pt:
-        pt.set_param("build_wide8", 1)
         pt.create_buffers((32, 32), flat)
-        for variant in (3, 5, 0, 1):
+        for variant in (3, 0, 1):
             pt.set_trace_variant(variant)
             t, nrm, mat, side = pt.intersect_rays(rays)
             assert np.array_equal(t >= 0, m), variant
@@ -484,8 +473,7 @@ def test_instance_ties_and_carried_hits(pkg, orc):
     assert not np.any(recs["material_id"][m] == mats["a"])
     # and whole frames of that scene
     ref = orc.render_streaming(flat, s.camera, 96, 64, 0, 3, 8)
-    for variant, fif, params in ((0, 1, ()), (3, 1, ()), (3, 6, (("batch_frames", 3),)), (1, 2, ()), (5, 1, ()),
-                                 (5, 6, (("batch_frames", 3),))):
+    for variant, fif, params in ((0, 1, ()), (3, 1, ()), (3, 6, (("batch_frames", 3),)), (1, 2, ())):
         got = frames(pkg, s, flat, 96, 64, 3, 8, variant=variant, fif=fif, params=params)
         assert np.array_equal(got["color"], ref["color"]) and got["stats"]["rays_total"] == ref["rays"], (variant, fif)
 
