@@ -9,6 +9,11 @@ primary rays included.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|2|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts its own N ranks: a child
+`torch.distributed.run` (one rank per GPU, RCCL), spawned before this process has touched the GPU, whose JSON line and
+exit code it hands on.  Fewer than N devices is an error unless --rehearse-on-one-gpu is given (all ranks on cuda:0,
+gloo: the N > 1 code path on a one-GPU box, not a scaling number).
+
 --config 3 (default)  the headline: 1M-triangle heightfield + 3 spheres, 1920x1080, 8 bounces
 --config 2            Cornell box + two instances of the 69,984-triangle mesh, 1280x720, 8 bounces (N=1)
 --config 5            config 3's scene, 1 spp + the A-Trous denoiser after EVERY frame, presented every frame
@@ -89,7 +94,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--no-events", action="store_true", help="do not time the trace kernel with HIP events (diagnostic)")
-    ap.add_argument("--cpu-sample", type=str, default="", help="resolution of the CPU-oracle sample frame (default: the full frame)")
+    ap.add_argument("--cpu-sample", type=str, default="", help="resolution of the CPU-oracle sample frames (default: the full frame)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="iterations the CPU oracle renders (cpu_baseline sample and parity frame): "
+                                                               "8 full frames are about 15 s on 16 threads")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (the GPU box's CPU share for one GPU is 16)")
     return ap.parse_args()
 
@@ -109,7 +116,7 @@ def pmc_record(name, frames_per_launch):
     return rec
 
 
-def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, pmc_scene=True):
+def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, pmc_scene=True, pixels=0, frames=0):
     """SURVEY 8(d) pricing of the closest-hit launches of the timed region.  pmc_scene: the counter records under
     profiles/ were taken on THIS scene (config 3); otherwise traffic / valu are null."""
     scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
@@ -152,9 +159,31 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
         "note": "the kernel's working set (27 MB of nodes + 48 MB of triangles + path state of the batch) is served "
                 "by L2 / Infinity Cache; it is bound by VALU issue at about half lane utilisation, see valu",
     }
+    # where the launch time goes, bounce by bounce (primary rays = bounce 0): rays, launch time (HIP events), node visits
+    # and triangle tests per ray, and the same SURVEY 8(d) pricing per bounce
+    per_bounce = []
+    for b in range(MB):
+        if not paths_timed[b]:
+            continue
+        nb, tb = scale[b] * counted["node_visits"][b], scale[b] * counted["tri_tests"][b]
+        bytes_b = paths_timed[b] * 52 + nb * 32 + tb * 48
+        ms_b = prof["trace_ms"][b]
+        per_bounce.append({"bounce": b, "rays": int(paths_timed[b]), "trace_ms": round(ms_b, 3), "launches": int(prof["trace_launches"][b]),
+                           "node_visits_per_ray": round(nb / paths_timed[b], 2), "tri_tests_per_ray": round(tb / paths_timed[b], 2),
+                           "ns_per_ray": round(ms_b * 1e6 / paths_timed[b], 3) if ms_b > 0 else None,
+                           "frac": round(bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_b > 0 else None})
+    roof["per_bounce"] = per_bounce
+    # SURVEY 8(d)'s whole-frame figure: B = sum_b n_b * 168 + node visits * 32 + triangle tests * 48 + P * (65 + 56) bytes per
+    # frame over the wall time of a frame (all kernels, not only the closest-hit launches)
+    if pixels and frames and elapsed > 0:
+        frame_bytes = (rays * 168 + nodes * 32 + tris * 48) / frames + pixels * 121
+        roof["frame_level"] = {"bytes_per_frame": round(frame_bytes), "ms_per_frame": round(elapsed / frames * 1e3, 4),
+                               "achieved": round(frame_bytes * frames / elapsed / 1e9, 2),
+                               "frac": round(frame_bytes * frames / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                               "pricing": "SURVEY 8(d): sum_b n_b*168 + node_visits*32 + tri_tests*48 + P*(65+56) bytes per frame / wall time per frame"}
     sq = pmc_record("pmc_sq_%d.json", frames_per_launch) if pmc_scene else None
     if sq is not None:
-        roof["valu"] = {k: sq.get(k) for k in ("valu_busy_frac", "valu_pipe_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
+        roof["valu"] = {k: sq.get(k) for k in ("valu_pipe_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
                                                 "salu_inst_per_ray", "l2_hit_frac", "wave_occupancy_frac", "frames_per_launch",
                                                 "matches_this_run", "source")}
     return roof
@@ -254,6 +283,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_rank = []   # N > 1: every rank's own rays and elapsed time of the last timed() region
+
     def timed(tracer, steps, warmup):
         for _ in range(warmup):
             tracer.path_trace(scene.camera)
@@ -273,7 +304,11 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         rays = tracer.stats()["rays_total"] - rays0
         prof = tracer.profile()
         tracer.set_profiling(False, False)
+        per_rank.clear()
         if world > 1:   # max over ranks of the elapsed time, sum of rays
+            mine = [None] * world
+            dist.all_gather_object(mine, {"rank": rank, "rays": int(rays), "elapsed_ms": round(elapsed * 1e3, 4)})
+            per_rank.extend(mine)
             t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -295,26 +330,99 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
 
     elapsed, rays, prof, first_iter = timed(pt, args.steps, args.warmup)
     last_live = pt.stats()["last_live"]
+    ranks_detail = list(per_rank)
+
+    # N > 1: the present-time gather on its own (SURVEY config 4: "RCCL gather time reported separately").  Both
+    # transports, five presents each after the timed region: the torch.distributed gather (RCCL; gloo in a rehearsal)
+    # timed with events on rank 0's stream from the first byte leaving to the frame being in row order, and the
+    # library's one-kernel pull over mapped peer buffers (ptc_gather_frame, device time from ptc_gather_last_us).
+    gather = None
+    if world > 1:
+        gather = {"bytes_per_present": int(sum(len(rr) for rr in rank_rows[1:]) * W * 12),
+                  "transport_in_timed_region": args.gather, "backend": "gloo (rehearsal)" if rehearse else "nccl (RCCL)"}
+        saved = args.gather
+        args.gather = "rccl"
+        us = []
+        for _ in range(5):
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            present(pt)
+            e1.record()
+            torch.cuda.synchronize()
+            us.append(e0.elapsed_time(e1) * 1e3)
+        gather["rccl_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
+        gather["rccl_note"] = "pack + dist.gather + index_copy into row order, rank 0's stream, median of 5"
+        # the library's gather: handles once, then publish / barrier / pull
+        try:
+            handle, err = (pt.band_export() if rank else b""), None
+        except Exception as exc:   # noqa: BLE001 -- reported, not fatal: the RCCL figure stands
+            handle, err = None, repr(exc)
+        handles = [None] * world
+        dist.all_gather_object(handles, (handle, err))
+        state = [None]
+        if rank == 0:
+            try:
+                for r in range(1, world):
+                    if handles[r][1]:
+                        raise RuntimeError(f"rank {r}: {handles[r][1]}")
+                    pt.band_import(r, handles[r][0])
+            except Exception as exc:   # noqa: BLE001
+                state = [repr(exc)]
+        dist.broadcast_object_list(state, src=0)
+        if state[0] is None:
+            us = []
+            for _ in range(5):
+                if rank:
+                    pt.band_publish("color")
+                dist.barrier()
+                if rank == 0:
+                    pt.gather_frame("color", frame.data_ptr())
+                    us.append(pt.gather_last_us())
+                dist.barrier()
+            gather["ipc_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
+            gather["ipc_note"] = ("ptc_gather_frame: one kernel on the root reads every rank's band where it lies (HIP IPC "
+                                  "mapping; xGMI between GPUs) and writes row order; device time, median of 5")
+        else:
+            gather["ipc_us"], gather["ipc_note"] = None, "library gather unavailable here: " + state[0]
+        args.gather = saved
     counted = count_tests(pt, first_iter, args.steps)
+    # parity leg, GPU side: THE TRACER THAT WAS JUST TIMED (same context, slots, streams, launch plan) restarted and run
+    # for the iterations the CPU oracle renders below; compared bit for bit there
+    timed_frames = None
+    cw, ch = (int(v) for v in args.cpu_sample.split("x")) if args.cpu_sample else (W, H)
+    cpu_frames = max(1, min(args.cpu_frames, args.steps))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and (cw, ch) == (W, H):
+        pt.restart()
+        r0 = pt.stats()["rays_total"]
+        for _ in range(cpu_frames):
+            pt.path_trace(scene.camera)
+        timed_frames = {k: pt.download(k) for k in ("color", "normal", "depth")}
+        st = pt.stats()
+        timed_frames["rays"] = st["rays_total"] - r0
+        timed_frames["last_live"] = st["last_live"]
     # (the counter records under profiles/ were taken on the default workload with the default kernel)
     pmc_scene = args.grid == "1001x501" and (W, H, MB) == (1920, 1080, 8) and args.trace_variant in (-1, 3) and world == 1
-    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=pmc_scene)
+    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=pmc_scene,
+                              pixels=W * H // world, frames=args.steps)
     slow_rays = sum(prof["slow_rays"])
 
     # the tuned schedule on the same workload (only when the timed region above was too short to show it)
     steady = None
     if not args.no_extras and (batch != 32 or args.steps < 256):
-        if batch != 32:
+        tuned_streams = args.streams or (2 if world <= 2 else 4)   # (not the single stream of a short timed region)
+        if batch != 32 or streams != tuned_streams:
             pt.close()
-            pt = make_tracer(32, streams)
+            pt = make_tracer(32, tuned_streams)
         s_el, s_rays, s_prof, s_first = timed(pt, 256, 64)
         s_counted = count_tests(pt, s_first, 4)
-        s_roof = trace_roofline(s_prof, s_counted, list(s_prof["paths"]), MB, s_el, 32, pmc_scene=pmc_scene)
+        s_roof = trace_roofline(s_prof, s_counted, list(s_prof["paths"]), MB, s_el, 32, pmc_scene=pmc_scene, pixels=W * H // world, frames=256)
         steady = {"value": round(s_rays / s_el / 1e6, 3), "unit": "Mrays/s", "steps": 256, "warmup": 64, "frames_per_launch": 32,
-                  "frames_in_flight": streams * 32, "ms_per_step": round(s_el / 256 * 1e3, 4),
+                  "frames_in_flight": tuned_streams * 32, "ms_per_step": round(s_el / 256 * 1e3, 4),
                   "roofline_frac": s_roof["frac"], "roofline_achieved": s_roof["achieved"],
                   "avg_launch_us": s_roof["avg_launch_us"], "traffic": s_roof["traffic"],
-                  "frac_requested": s_roof["frac_requested"]}
+                  "frac_requested": s_roof["frac_requested"], "concurrent_launches": s_roof["concurrent_launches"],
+                  "frame_level_frac": (s_roof.get("frame_level") or {}).get("frac"), "per_bounce": s_roof["per_bounce"]}
     pt.close()
 
     # single-frame latency: strictly serial frames, and the viewer pattern (app.cpp:141-170 presents every frame)
@@ -347,30 +455,34 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     cpu_baseline = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         orc = graft.load_oracle()
-        cw, ch = (int(v) for v in args.cpu_sample.split("x")) if args.cpu_sample else (W, H)
         sh = orc.SceneHandle(flat)
         cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
         t0 = time.perf_counter()
-        ref = orc.render_streaming(flat, scene.camera, cw, ch, 0, 1, MB, nthreads=cores, scene_handle=sh)
+        ref = orc.render_streaming(flat, scene.camera, cw, ch, 0, cpu_frames, MB, nthreads=cores, scene_handle=sh)
         dt = time.perf_counter() - t0
         cpu_baseline = {"value": round(ref["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                        "sample": f"1 frame of the same scene (same {len(flat.indices) // 3}-triangle BVH, {MB} bounces) at "
-                                  f"{cw}x{ch}: {ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so (CPU restatement; "
-                                  "the reference has no CPU path)"}
-        # the production schedule's iteration 0 of the same frame against that oracle frame
-        with pkg.PathTracer(device=local_rank, max_bounces=MB) as cp:
-            cp.set_param("frames_in_flight", 2)
-            cp.create_buffers((cw, ch), flat)
-            cp.max_iterations = 1
-            cp.path_trace(scene.camera)
-            got = {k: cp.download(k) for k in ("color", "normal", "depth")}
-            st = cp.stats()
+                        "sample": f"{cpu_frames} accumulated iterations of the same scene (same {len(flat.indices) // 3}-triangle BVH, "
+                                  f"{MB} bounces) at {cw}x{ch}: {ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so (CPU "
+                                  "restatement; the reference has no CPU path)"}
+        if timed_frames is not None:
+            got, what = timed_frames, "the timed tracer itself (same context and schedule: %d frames per launch, %d stream(s)), restarted" % (batch, streams)
+        else:   # a reduced --cpu-sample resolution: a tracer of that size with the library's default schedule
+            with pkg.PathTracer(device=local_rank, max_bounces=MB) as cp:
+                cp.create_buffers((cw, ch), flat)
+                cp.max_iterations = cpu_frames
+                for _ in range(cpu_frames):
+                    cp.path_trace(scene.camera)
+                got = {k: cp.download(k) for k in ("color", "normal", "depth")}
+                st = cp.stats()
+                got["rays"], got["last_live"] = st["rays_total"], st["last_live"]
+            what = "a tracer of the sample's size, default schedule"
         d = got["color"].astype(np.float64) - ref["color"].astype(np.float64)
-        parity = {"against": "oracle frame of cpu_baseline (iteration 0, %dx%d, default schedule)" % (cw, ch),
+        parity = {"against": "the CPU oracle's %d accumulated iterations at %dx%d (the frames of cpu_baseline)" % (cpu_frames, cw, ch),
+                  "gpu_side": what,
                   "mse": float(np.mean(np.sum(d * d, axis=-1))),
                   "bit_exact": bool(all(np.array_equal(got[k], ref[k]) for k in ("color", "normal", "depth"))),
-                  "live_equal": bool(st["last_live"] == [int(v) for v in ref["live"][-1][:MB]]),
-                  "rays_equal": bool(st["rays_total"] == ref["rays"]), "tolerance_mse": 1e-4}
+                  "live_equal": bool(got["last_live"][:MB] == [int(v) for v in ref["live"][-1][:MB]]),
+                  "rays_equal": bool(got["rays"] == ref["rays"]), "tolerance_mse": 1e-4}
 
     if rank != 0:
         return None
@@ -395,6 +507,9 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                    "startup": {"scene_upload_ms": startup, "note": "ptc_upload_scene of the scene without BVH: reference BVH (bit-identical "
                                "to the host builder's) and traversal layouts built on the GPU", "host_bvh_builder_s": round(bvh_build_s, 3)}},
         "roofline": roofline,
+        "gather": gather,
+        "ranks": ranks_detail or None,
+        "rccl_ranks": (0 if rehearse else world) if world > 1 else None,
         "parity": parity,
         "steady_state": steady,
         "latency": latency,
@@ -446,9 +561,10 @@ def run_config2(args, pkg, torch, local_rank):
         pt.path_trace(scene.camera)
     counted = pt.profile()
     pt.set_profiling(False, False)
-    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=False)
-    roofline["kernel"] += "; one launch per mesh instance and bounce"
-    roofline["note"] = "3.3 node visits per ray: ray fetch, hit write and the per-launch tails weigh more than in config 3"
+    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=False, pixels=W * H, frames=args.steps)
+    roofline["kernel"] = roofline["kernel"].replace("k_traverse4 (", "k_traverse4m (both instances of the mesh in one launch per bounce; ")
+    roofline["note"] = ("%.1f node visits per ray: the fixed round trips of a ray (fetch, root, winner's parent box and normal, store) "
+                        "weigh more than its walk" % roofline["node_visits_per_ray"])
     pt.close()
     cpu_baseline = None
     if not args.no_cpu_baseline:
@@ -543,15 +659,41 @@ def run_config5(args, pkg, torch, local_rank):
     }
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run, N ranks on this
+    node, as a CHILD process (this one has not initialised HIP: torch.cuda.device_count() does not), and hand its exit
+    code on.  The ranks print the JSON line themselves (rank 0)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.rehearse_on_one_gpu:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s); pass --rehearse-on-one-gpu to run "
+                         f"the {args.gpus}-rank code path on one device (not a scaling measurement)\n")
+        return 2
+    if args.rehearse_on_one_gpu and have < 1:
+        sys.stderr.write("bench.py: no GPU\n")
+        return 2
+    with socket.socket() as sock:   # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1 and args.config != 3:
         raise SystemExit("--config 2 and 5 are single-GPU workloads")

@@ -3,8 +3,10 @@
 // following the call sequence of execute_cli_version (src/cli/cli.cpp:62-116): read scene, create_buffers,
 // max_iterations = spp, spp x path_trace, synchronize, send_to_preview, write PNG, stage timings.
 // Extra flags: --max-bounces N (the reference's cap is a compile-time 50), --denoise, --method, --gpu,
-// --dump-scene FILE (flattened scene arrays, for tests; needs no GPU), --gpus N.  Without -o the reference opens its
-// GLFW viewer; this build is headless and says so.
+// --dump-scene FILE (flattened scene arrays, for tests; needs no GPU), --gpus N, --display final|color|normal|depth
+// (DisplayBufferType of send_to_preview, path_tracer.cu:487-520: which buffer the PNG shows), --dump-raw FILE (the
+// accumulated float framebuffers as they are: "PTRF", width, height, 7 as uint32, then colour rgb, normal xyz and
+// depth planes as float32).  Without -o the reference opens its GLFW viewer; this build is headless and says so.
 //
 // --gpus N: one PROCESS per GPU (forked before anything touches HIP), rank r on device r % device_count.  The frame's
 // rows are dealt to the ranks in blocks of 8 (ptc_set_interleave: sky rows are cheap, terrain rows expensive), the
@@ -42,6 +44,8 @@ struct CliConfigurations {  // configurations.hpp:11-15
   int gpu = 0;
   int gpus = 1;
   std::optional<std::string> dump_scene;
+  std::optional<std::string> dump_raw;
+  DisplayBufferType display = DisplayBufferType::final;
 };
 
 void usage()
@@ -56,7 +60,9 @@ void usage()
                "      --method M       streaming (default) | megakernel\n"
                "      --gpu N          HIP device ordinal\n"
                "      --gpus N         split the frame's rows over N processes / GPUs (rank r on device r %% device count)\n"
-               "      --dump-scene F   write the flattened scene to F and exit (no GPU needed)\n");
+               "      --dump-scene F   write the flattened scene to F and exit (no GPU needed)\n"
+               "      --display D      buffer the image shows: final (default) | color | normal | depth\n"
+               "      --dump-raw F     also write the accumulated float buffers (colour, normal, depth) to F\n");
 }
 
 CliConfigurations parse_cli_args(int argc, char** argv)
@@ -84,6 +90,18 @@ CliConfigurations parse_cli_args(int argc, char** argv)
     else if (a == "--gpu") c.gpu = std::stoi(need("gpu"));
     else if (a == "--gpus") c.gpus = std::stoi(need("gpus"));
     else if (a == "--dump-scene") c.dump_scene = need("dump-scene");
+    else if (a == "--dump-raw") c.dump_raw = need("dump-raw");
+    else if (a == "--display") {
+      const std::string d = need("display");
+      if (d == "final") c.display = DisplayBufferType::final;
+      else if (d == "color") c.display = DisplayBufferType::color;
+      else if (d == "normal") c.display = DisplayBufferType::normal;
+      else if (d == "depth") c.display = DisplayBufferType::depth;
+      else {
+        std::fprintf(stderr, "Option '--display': unknown buffer '%s' (final, color, normal, depth)\n", d.c_str());
+        std::exit(1);
+      }
+    }
     else if (!a.empty() && a[0] == '-') {
       std::fprintf(stderr, "Option '%s' does not exist\n", a.c_str());
       std::exit(1);
@@ -133,6 +151,25 @@ void dump_vec(std::ofstream& out, const std::vector<T>& v)
   const uint64_t n = v.size();
   out.write(reinterpret_cast<const char*>(&n), 8);
   out.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(n * sizeof(T)));
+}
+
+// --dump-raw: the float framebuffers as they are.  fetch(which, dst) fills width*height*{3,3,1} floats.
+template <typename Fetch>
+bool write_raw(const std::string& path, uint32_t width, uint32_t height, Fetch fetch)
+{
+  std::ofstream out(path, std::ios::binary);
+  if (!out) return false;
+  const uint32_t head[3] = {width, height, 7u};
+  out.write("PTRF", 4);
+  out.write(reinterpret_cast<const char*>(head), sizeof head);
+  std::vector<float> plane((size_t)width * height * 3u);
+  const int which[3] = {PTC_BUF_COLOR, PTC_BUF_NORMAL, PTC_BUF_DEPTH};
+  for (int k = 0; k < 3; ++k) {
+    const size_t floats = (size_t)width * height * (which[k] == PTC_BUF_DEPTH ? 1u : 3u);
+    fetch(which[k], plane.data());
+    out.write(reinterpret_cast<const char*>(plane.data()), (std::streamsize)(floats * sizeof(float)));
+  }
+  return (bool)out;
 }
 
 // ---- --gpus N -------------------------------------------------------------------------------------------------
@@ -189,14 +226,17 @@ try {
   stopwatch.end_stage("Initialization");
   path_tracer.max_iterations = spp;
   for (int i = 0; i < spp; ++i) path_tracer.path_trace(scene_desc.camera, resolution);
-  if (rank != 0) check(ptc_band_publish(path_tracer.handle(), PTC_BUF_COLOR), "band_publish");
+  // the rows the image will show (ptc_gather_present_rgba8 gathers the buffer of its display type)
+  const int shown = configs.display == DisplayBufferType::normal ? PTC_BUF_NORMAL
+                    : configs.display == DisplayBufferType::depth ? PTC_BUF_DEPTH : PTC_BUF_COLOR;
+  if (rank != 0) check(ptc_band_publish(path_tracer.handle(), shown), "band_publish");
   else path_tracer.synchronize();
   sh->rays[rank] = path_tracer.stats().rays_total;
   if (!barrier(sh, world)) throw std::runtime_error("another rank failed while tracing");
   stopwatch.end_stage("Path Tracing");
   if (rank == 0) {
     std::vector<uchar4> buffer((size_t)resolution.width * resolution.height);
-    check(ptc_gather_present_rgba8(path_tracer.handle(), buffer.data(), 0, PTC_DISPLAY_FINAL), "gather_present");
+    check(ptc_gather_present_rgba8(path_tracer.handle(), buffer.data(), 0, static_cast<int>(configs.display)), "gather_present");
     const fs::path output_path{*configs.output_filename};
     if (output_path.extension() == ".png") {
       if (!write_png(output_path.string(), (int)resolution.width, (int)resolution.height, buffer.data()))
@@ -205,6 +245,25 @@ try {
       std::fprintf(stderr, "%s has an unrecognized extension\n", output_path.string().c_str());
     }
     stopwatch.end_stage("Gather + write image file");
+  }
+  if (configs.dump_raw) {  // every buffer is one more publish / gather round
+    const int which[3] = {PTC_BUF_COLOR, PTC_BUF_NORMAL, PTC_BUF_DEPTH};
+    std::vector<std::vector<float>> planes(3);
+    for (int k = 0; k < 3; ++k) {
+      if (!barrier(sh, world)) throw std::runtime_error("another rank failed");  // the root has pulled the previous rows
+      if (rank != 0) check(ptc_band_publish(path_tracer.handle(), which[k]), "band_publish");
+      if (!barrier(sh, world)) throw std::runtime_error("another rank failed while publishing");
+      if (rank == 0) {
+        planes[k].resize((size_t)resolution.width * resolution.height * (which[k] == PTC_BUF_DEPTH ? 1u : 3u));
+        check(ptc_gather_frame(path_tracer.handle(), which[k], planes[k].data(), 0), "gather_frame");
+      }
+    }
+    if (rank == 0) {
+      int k = 0;
+      if (!write_raw(*configs.dump_raw, resolution.width, resolution.height,
+                     [&](int, float* dst) { std::memcpy(dst, planes[k].data(), planes[k].size() * sizeof(float)); ++k; }))
+        std::fprintf(stderr, "Failed to write %s\n", configs.dump_raw->c_str());
+    }
   }
   if (!barrier(sh, world)) throw std::runtime_error("another rank failed at the end");  // peers keep their rows until here
   if (rank == 0) {
@@ -331,7 +390,7 @@ try {
   stopwatch.end_stage("Path Tracing");
 
   std::vector<uchar4> buffer((size_t)resolution.width * resolution.height);
-  path_tracer.send_to_preview(buffer.data(), resolution);
+  path_tracer.send_to_preview(buffer.data(), resolution, configs.display);
   const fs::path output_path{*configs.output_filename};
   if (output_path.extension() == ".png") {
     if (!write_png(output_path.string(), (int)resolution.width, (int)resolution.height, buffer.data()))
@@ -339,6 +398,11 @@ try {
   } else {
     std::fprintf(stderr, "%s has an unrecognized extension\n", output_path.string().c_str());
   }
+  if (configs.dump_raw &&
+      !write_raw(*configs.dump_raw, resolution.width, resolution.height, [&](int which, float* dst) {
+        if (ptc_download(path_tracer.handle(), which, dst, 0) < 0) throw std::runtime_error(ptc_last_error(path_tracer.handle()));
+      }))
+    std::fprintf(stderr, "Failed to write %s\n", configs.dump_raw->c_str());
   stopwatch.end_stage("Write image file");
 
   const ptc_stats st = path_tracer.stats();

@@ -96,3 +96,69 @@ def test_cli_image_equals_python_path(pkg, tmp_path, scene_file):
             pt.path_trace(scene.camera)
         want = pt.send_to_preview()
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def _read_raw(path):
+    data = open(path, "rb").read()
+    assert data[:4] == b"PTRF"
+    w, h, ch = struct.unpack_from("<III", data, 4)
+    assert ch == 7 and len(data) == 16 + 4 * 7 * w * h
+    f = np.frombuffer(data, dtype="<f4", offset=16)
+    P = w * h
+    return {"color": f[:3 * P].reshape(h, w, 3), "normal": f[3 * P:6 * P].reshape(h, w, 3), "depth": f[6 * P:].reshape(h, w)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_cli_display_views_and_raw_dump(pkg, tmp_path, gpus):
+    """hip_pt --display normal|depth|color writes send_to_preview's views (path_tracer.cu:487-520: n*0.5+0.5; 1/depth
+    with alpha 1) and --dump-raw the float framebuffers behind them; one process and --gpus 2 (rows dealt in blocks of
+    8, the ranks publish the buffer the image shows)."""
+    from PIL import Image
+    _ensure_cli()
+    scene_file, spp, mb = "cornell_mesh.json", 2, 5
+    scene = pkg.json_parser.scene_from_json(os.path.join(ROOT, "assets", "scenes", scene_file))
+    w, h = scene.resolution
+    views, raws = {}, {}
+    if gpus == 1:
+        with pkg.PathTracer(max_bounces=mb) as pt:
+            pt.create_buffers(scene.resolution, scene)
+            pt.max_iterations = spp
+            for _ in range(spp):
+                pt.path_trace(scene.camera)
+            for name in ("color", "normal", "depth"):
+                views[name] = pt.send_to_preview(display_type=getattr(pkg.DisplayBufferType, name))
+                raws[name] = pt.download(name)
+    else:
+        parts = {k: [] for k in ("color", "normal", "depth")}
+        rparts = {k: [] for k in ("color", "normal", "depth")}
+        for rank in range(gpus):
+            with pkg.PathTracer(max_bounces=mb) as pt:
+                pt.create_buffers(scene.resolution, scene)
+                pt.set_interleave(rank, gpus, 8)
+                pt.set_param("slot_offset", rank * w * h)
+                pt.max_iterations = spp
+                for _ in range(spp):
+                    pt.path_trace(scene.camera)
+                for name in parts:
+                    parts[name].append(pt.send_to_preview(display_type=getattr(pkg.DisplayBufferType, name)))
+                    rparts[name].append(pt.download(name))
+        for name in parts:
+            views[name] = pkg.bands.assemble_interleaved(parts[name], h, gpus, 8)
+            raws[name] = pkg.bands.assemble_interleaved(rparts[name], h, gpus, 8)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for name in ("color", "normal", "depth"):
+        out, raw = tmp_path / f"{name}.png", tmp_path / f"{name}.raw"
+        cmd = [HIP_PT, "scenes/" + scene_file, "-o", str(out), "--spp", str(spp), "--max-bounces", str(mb), "--display", name,
+               "--dump-raw", str(raw)] + (["--gpus", str(gpus)] if gpus > 1 else [])
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = np.array(Image.open(out))
+        assert got.shape == views[name].shape and np.array_equal(got, views[name]), name
+        dumped = _read_raw(raw)
+        for k in ("color", "normal", "depth"):
+            assert np.array_equal(dumped[k], raws[k].reshape(dumped[k].shape)), (name, k)
+    assert np.all(views["depth"][..., 3] == 1) and np.all(views["normal"][..., 3] == 255)   # preview_depth_kernel's alpha
+    r = subprocess.run([HIP_PT, "scenes/" + scene_file, "-o", str(tmp_path / "x.png"), "--display", "albedo"], cwd=ROOT,
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown buffer" in r.stderr

@@ -80,3 +80,29 @@ def test_band_handle_geometry_is_checked_on_import(pkg):
             with pytest.raises(pkg.PtcError) as e:
                 root.band_import(1, tampered(**bad))
             assert e.value.code == capi.PTC_ERR_INVALID, bad
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 --rehearse-on-one-gpu --steps 20 --warmup 5` with no launcher around it: bench.py
+    spawns its two ranks itself (a child torch.distributed.run, before the parent touches the GPU) and rank 0 prints
+    ONE line with n_gpus 2, the gather time on its own, and both ranks' rays.  Without --rehearse-on-one-gpu the same
+    request on this one-GPU box must fail loudly instead of measuring one GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "20", "--warmup", "5",
+           "--no-extras"]
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0
+    assert d["rccl_ranks"] == 0 and "gloo" in d["gather"]["backend"]          # a rehearsal says so
+    assert d["gather"]["rccl_us"] > 0 and d["gather"]["ipc_us"] > 0, d["gather"]
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["rays"] > 0 for r in d["ranks"])
+    assert abs(sum(r["rays"] for r in d["ranks"]) - d["config"]["rays_per_step"] * 20) <= 20
+    import torch
+    if torch.cuda.device_count() < 2:
+        proc = subprocess.run(cmd[:4] + cmd[5:], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert proc.returncode != 0 and '"metric"' not in proc.stdout and "--rehearse-on-one-gpu" in proc.stderr
