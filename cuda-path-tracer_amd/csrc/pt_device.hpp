@@ -23,8 +23,17 @@ constexpr int kWorkSlots = 4;
 // Traversal stack entries per lane the four-wide walk keeps in LDS (6 KiB per wavefront at 24); deeper entries go to
 // DScene::spill.  ONE constant for the kernels' LDS arrays and the host's DScene::lds_cap / spill sizing: a build with
 // -DPT_T4_LDS=16 against a host that assumed 24 wrote past its stack (round-2 A/B fault).
+// PT_QUAD_FETCH: the four lanes of a quad fetch the four quarters of ONE 64-byte record per load instruction, straight
+// into LDS (k_traverse4, see there); its 4 KiB record image per wavefront is paid for with stack entries.
+#ifndef PT_QUAD_FETCH
+#define PT_QUAD_FETCH 1
+#endif
 #ifndef PT_T4_LDS
+#if PT_QUAD_FETCH
+#define PT_T4_LDS 10
+#else
 #define PT_T4_LDS 24
+#endif
 #endif
 constexpr int kLds4 = PT_T4_LDS;
 static_assert(kLds4 >= 4 && kLds4 <= kStackDepth, "PT_T4_LDS out of range");
@@ -184,6 +193,7 @@ struct DeviceCounters {
   uint32_t flags;
   uint32_t slow_count;             // rays set aside for the exact redo by the running traversal launch
   uint32_t waves_done;             // wavefronts of the running traversal launch that have signed off
+  uint32_t shade_ticket;           // k_shade_fused: next tile of this frame to be taken (zero between launches)
   unsigned long long rays_total;
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
@@ -281,6 +291,14 @@ void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHi
                   bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
                   const uint32_t* chunk_offsets, DFrame fb, DBand band, DeviceCounters* counters, uint8_t* octs,
                   const DBatchInfo& bi);
+// the end of a bounce in one pass (k_shade_fused): trailing sphere run [obj_begin, obj_end) + material + stable compaction +
+// final gather.  tile_desc: shade_tiles_per_frame(max_paths) descriptors per frame of the batch (tile_stride apart), zero
+// at allocation and never cleared; epoch: a number no earlier launch on these descriptors has used (1 .. 2^30 - 1)
+void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths in, DPaths out,
+                        DHits hits, uint32_t max_paths, bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
+                        unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb, DBand band,
+                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi);
+uint32_t shade_tiles_per_frame(uint32_t max_paths);
 void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi);
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);

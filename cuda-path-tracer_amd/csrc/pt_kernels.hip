@@ -951,6 +951,20 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   // explicitly an LDS pointer: as a generic pointer the pop below compiles to a flat load
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   lds_u32* stack = (lds_u32*)s_stack + threadIdx.x;
+#if PT_QUAD_FETCH
+  // Record image of the quad-cooperative fetch (see the loop): load instruction k puts lane L's 16 bytes at
+  // s_img[k * 64 + L] (LDS-DMA writes base + lane * 16), i.e. quarter-position m = L & 3 of the record owned by lane
+  // 4 * (L >> 2) + k.  Owner lane r = 4 Q + k therefore finds its record at s_img[k * 64 + 4 Q ..+3]; the quarters sit
+  // rotated by k inside it (position p holds quarter (p - k) & 3 -- the fetching lanes rotate their SOURCE address), so
+  // that the sixteen lanes of a ds_read_b128 pass, which read the same quarter j of sixteen records, hit sixteen
+  // different bank groups: lane r reads position (j + k) & 3.
+  static_assert(kTriVec4 == 4u, "the quad fetch reads 64-byte records");
+  typedef uint32_t img_u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ img_u32x4 s_img[4 * kWave];
+  typedef __attribute__((address_space(3))) img_u32x4 lds_u4;
+  const uint32_t quad_m = threadIdx.x & 3u;
+  const lds_u4* my_rec = (const lds_u4*)s_img + quad_m * 64u + (threadIdx.x & ~3u);
+#endif
   const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
   // `slot` below is batch-global (frame * bi.stride + slot in the frame); flags, the slow-ray list and the
   // test tallies of the whole batch go to frame 0's counters
@@ -1261,6 +1275,50 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     // lane falls back to is read from LDS meanwhile.  Vector-memory instructions and dependent round trips are
     // what this loop is bound by (lesson x): four loads and one wait per iteration, where
     // separate node and triangle phases needed seven loads and two waits.
+#if PT_QUAD_FETCH
+    // Quad-cooperative fetch.  A lane's step needs one 64-byte record (node or triangle) from an address of its own.
+    // Fetched by the lane itself that is four 16-byte loads to one line: the L1's address path (one tag lookup per
+    // distinct line and instruction) saw 36 lookups per instruction, 144 per iteration, and was the busiest unit of the
+    // kernel.  Here load instruction k serves the records of lanes 4 Q + k: the four lanes of quad Q
+    // fetch its four quarters -- one lookup per quad, 16 per instruction, 64 per iteration -- and the data goes straight
+    // to LDS (global_load_lds_dwordx4: no VGPR destination, no transpose in registers); every lane then reads its own
+    // record back with four conflict-free ds_read_b128.  All 64 lanes take part whatever their own state (an idle lane
+    // fetches for its quad and owns a dummy record).
+    const bool is_leaf = (cur & kLeafBit) != 0u;
+    const uint32_t index = cur & ~kLeafBit;
+    uint4 q0, q1, q2, q3;
+    uint32_t below;
+    {
+      const char* rec = !active ? reinterpret_cast<const char*>(tris)
+                        : is_leaf ? reinterpret_cast<const char*>(tris) + 64u * (size_t)index
+                                  : reinterpret_cast<const char*>(sc.cur.bvh4q) + 64u * (size_t)index;
+      const uint32_t lo = (uint32_t)(uintptr_t)rec, hi = (uint32_t)((uintptr_t)rec >> 32);
+      typedef __attribute__((address_space(1))) const void gptr_t;
+      typedef __attribute__((address_space(3))) void lptr_t;
+#define PT_QUAD_LOAD(k)                                                                                                     \
+  {                                                                                                                         \
+    const uint32_t alo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, (k) * 0x55, 0xf, 0xf, false);                   \
+    const uint32_t ahi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, (k) * 0x55, 0xf, 0xf, false);                   \
+    const uint64_t src = (((uint64_t)ahi << 32) | alo) + (uint64_t)(((quad_m - (k)) & 3u) << 4);                           \
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)((lds_u4*)s_img + (k) * 64), 16, 0, 0);                         \
+  }
+      PT_QUAD_LOAD(0)
+      PT_QUAD_LOAD(1)
+      PT_QUAD_LOAD(2)
+      PT_QUAD_LOAD(3)
+#undef PT_QUAD_LOAD
+      below = peek();
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the four pieces are in LDS
+      asm volatile("" ::: "memory");
+      const img_u32x4 w0 = my_rec[(0u + quad_m) & 3u], w1 = my_rec[(1u + quad_m) & 3u];
+      const img_u32x4 w2 = my_rec[(2u + quad_m) & 3u], w3 = my_rec[(3u + quad_m) & 3u];
+      q0 = make_uint4(w0.x, w0.y, w0.z, w0.w);
+      q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
+      q2 = make_uint4(w2.x, w2.y, w2.z, w2.w);
+      q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
+    }
+    if (active) {
+#else
     if (active) {
       const bool is_leaf = (cur & kLeafBit) != 0u;
       const uint32_t index = cur & ~kLeafBit;
@@ -1293,6 +1351,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));  // ... and nothing reads them above this line
       const uint4 q0 = make_uint4(w0.x, w0.y, w0.z, w0.w), q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
       const uint4 q2 = make_uint4(w2.x, w2.y, w2.z, w2.w), q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
+#endif
       if (!is_leaf) {
         if (kCount) ++tally.nodes;
         // 64-byte node: origin + power-of-two grid steps + 8-bit plane coordinates (Wide4Accel::nodes_q).  A plane
@@ -1686,6 +1745,251 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
     stnt(&out.t4[dst], make_float4(color.x, color.y, color.z, 0.0f));
     // direction octant of the new ray, for the coherence sort of the next bounce (k_sort_octant)
     if (octs) octs[dst] = (uint8_t)((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the end of a bounce in ONE pass: trailing sphere run + material + stable compaction + final gather
+// ------------------------------------------------------------------------------------------------
+// k_tail_count -> k_scan -> k_shade read every ray and hit record twice and put a one-workgroup scan between two
+// full-width launches.  This kernel does the three jobs in one pass over the slots (path_tracer.cu:292-315 material_kernel,
+// :454-457 stable_partition, :317-330 final gather; :78-100 for the sphere run that ends the object list):
+//   * a workgroup owns a TILE of 256 x kFuseK consecutive slots (every thread kFuseK of them, 256 apart: coalesced),
+//     loads ray + hit, finishes the closest hit (the trailing spheres), and knows from "is there a hit" alone which of
+//     its paths survive -- so the tile's survivor count is published after ONE round trip to memory;
+//   * the stable offset of the tile = survivors of all tiles before it, found by decoupled look-back over the tile
+//     descriptors (aggregate / inclusive prefix, Merrill & Garland): a wavefront reads up to 64 predecessors at once;
+//   * tiles are taken in TICKET order (one atomic per workgroup on the frame's counter line), not blockIdx order: a
+//     workgroup that waits for a predecessor's descriptor knows that predecessor is running or done, whatever else
+//     (the other stream's persistent traversal wavefronts) holds the chip's wavefront slots.  Blocks are numbered
+//     frame-fastest, so consecutive tickets of a batch go to different frames' counter lines;
+//   * descriptors carry the launch's epoch, so nothing has to be cleared between launches.
+// Same arithmetic and same slot order as the three kernels it replaces: images are bit-identical (tests).
+#ifndef PT_FUSE_K
+#define PT_FUSE_K 4
+#endif
+constexpr int kFuseK = PT_FUSE_K;
+constexpr uint32_t kFuseTile = 256u * kFuseK;
+constexpr unsigned long long kDescAggregate = 1ull << 32, kDescPrefix = 2ull << 32;
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
+  return v;
+}
+
+// exclusive prefix of `tile` (survivors of tiles [0, tile)), by the calling wavefront; every lane returns it
+__device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc, uint32_t tile, uint32_t epoch)
+{
+  uint32_t excl = 0u;
+  const int lane = (int)lane_id();
+  int pos = (int)tile - 1;
+  while (pos >= 0) {
+    const int idx = pos - lane;  // lane 0 = the nearest predecessor
+    for (;;) {
+      unsigned long long d = 0ull;
+      if (idx >= 0) d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool valid = idx >= 0;
+      const bool ready = !valid || (uint32_t)(d >> 34) == epoch;
+      const bool is_prefix = valid && ready && (d & kDescPrefix) != 0ull;
+      const uint64_t rdy = __ballot(ready), pm = __ballot(is_prefix);
+      if (pm != 0ull) {
+        const int p = __ffsll((unsigned long long)pm) - 1;  // nearest predecessor that knows its inclusive prefix
+        const uint64_t need = (p == 63) ? ~0ull : ((1ull << (p + 1)) - 1ull);
+        if ((rdy & need) == need) return excl + wave_sum(lane <= p ? (uint32_t)d : 0u);
+      } else if (rdy == ~0ull) {
+        excl += wave_sum(valid ? (uint32_t)d : 0u);
+        break;  // 64 aggregates and no prefix among them: look further back
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    pos -= kWave;
+  }
+  return excl;
+}
+
+template <bool kSpheres, bool kFirst>
+__global__ __launch_bounds__(256) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
+                                                     int staged, int bounce, int last_bounce, const uint32_t* slot_base,
+                                                     unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb,
+                                                     DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi)
+{
+  __shared__ uint32_t s_tile, s_excl;
+  __shared__ uint32_t s_cnt[kFuseK * 4];
+  const uint32_t frame = blockIdx.x % bi.count;  // frame-fastest: neighbouring blocks take their tickets on different lines
+  const uint32_t iteration = bi.iteration[frame];
+  const uint32_t acc_iteration = staged ? 0u : iteration;
+  const size_t fo = (size_t)frame * bi.stride;
+  if (octs) octs += fo;
+  in.o4 += fo;
+  in.d4 += fo;
+  in.t4 += fo;
+  out.o4 += fo;
+  out.d4 += fo;
+  out.t4 += fo;
+  hits.tp += fo;
+  hits.nm += fo;
+  tile_desc += (size_t)frame * tile_stride;
+  if (staged) {
+    fb.color4 += fo;
+    fb.nd4 += fo;
+  }
+  counters += frame;
+  const uint32_t n = counters->live[bounce];
+  const uint32_t tiles = (n + kFuseTile - 1u) / kFuseTile;
+  const uint32_t blocks_per_frame = gridDim.x / bi.count;
+  if (threadIdx.x == 0u) {
+    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every workgroup of the frame has its ticket once the last one is out: the next launch starts from zero
+    if (t + 1u == blocks_per_frame) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  if (tile >= tiles) {
+    if (tiles == 0u && tile == 0u && threadIdx.x == 0u) counters->live[bounce + 1] = 0u;  // nothing alive: nothing follows
+    return;
+  }
+  const uint32_t wave = threadIdx.x >> 6;
+
+  // ---- phase 1: rays and hits of the tile; the closest hit is final after the trailing sphere run ----
+  float4 o4[kFuseK], d4[kFuseK], tp[kFuseK], nm[kFuseK];
+  uint32_t have_nm = 0u, hit_mask = 0u;
+#pragma unroll
+  for (int j = 0; j < kFuseK; ++j) {
+    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    tp[j] = make_float4(-1.0f, 0.f, 0.f, 0.f);
+    nm[j] = o4[j] = d4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < n) {
+      o4[j] = ldnt(&in.o4[s]);
+      d4[j] = ldnt(&in.d4[s]);
+      if (!kFirst) tp[j] = ldnt(&hits.tp[s]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kFuseK; ++j) {
+    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    if (kSpheres && s < n) {
+      Ray ray;
+      ray.o = xyz(o4[j]);
+      ray.d = xyz(d4[j]);
+      ray.tmin = (__float_as_uint(o4[j].w) >> 31) ? 1e-5f : 1e-4f;
+      ray.tmax = tp[j].x >= 0.0f ? tp[j].x : FLT_MAX;
+      Hit rec;
+      bool changed = false;
+      sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
+      if (changed) {  // the record stays in registers: its only reader is this thread, a few lines down
+        tp[j] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
+        nm[j] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
+        have_nm |= 1u << j;
+      }
+    }
+    const bool hit = s < n && tp[j].x >= 0.0f;
+    hit_mask |= hit ? 1u << j : 0u;
+    const uint64_t live = __ballot(hit && !last_bounce);
+    if ((threadIdx.x & 63u) == 0u) s_cnt[j * 4 + (int)wave] = (uint32_t)__popcll(live);
+  }
+  // what phase 2 still needs from memory, requested before anybody waits for anything
+  float4 t4[kFuseK];
+#pragma unroll
+  for (int j = 0; j < kFuseK; ++j) {
+    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    t4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < n) t4[j] = ldnt(&in.t4[s]);
+    if (!kFirst && (hit_mask >> j & 1u) && !(have_nm >> j & 1u)) nm[j] = ldnt(&hits.nm[s]);
+  }
+  __syncthreads();
+  // ---- the tile's survivor count goes out (one round trip after the workgroup started) ----
+  uint32_t agg = 0u;
+#pragma unroll
+  for (int k = 0; k < kFuseK * 4; ++k) agg += s_cnt[k];
+  const unsigned long long tag = (unsigned long long)epoch << 34;
+  if (threadIdx.x == 0u)
+    __hip_atomic_store(&tile_desc[tile], tag | (tile == 0u ? kDescPrefix : kDescAggregate) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- phase 2: material_kernel per slot, in place: the new ray and throughput of a survivor take the registers of the
+  // old ones (nothing is written yet: where to is known only after the look-back, which by then has had the whole of
+  // this phase to resolve); paths that end go into the framebuffer ----
+  uint32_t surv_mask = 0u;
+#pragma unroll
+  for (int j = 0; j < kFuseK; ++j) {
+    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    f3 ro = xyz(o4[j]), rd = xyz(d4[j]), color = xyz(t4[j]);
+    uint32_t pixbits = __float_as_uint(o4[j].w);
+    if (s < n) {
+      const uint32_t pixel = pixbits & 0x7fffffffu;
+      const uint32_t local_pixel = band_local(band, pixel);
+      bool tmin_flag = (pixbits >> 31) != 0u;
+      if (!(hit_mask >> j & 1u)) {
+        // miss: throughput *= sky; the path ends (path_tracer.cu:304-307, 283-289)
+        color = color * background(rd);
+        if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, -rd, 1e6f);  // raygen defaults, ray_gen.cu:26-28
+        accumulate_color(fb.color4, local_pixel, acc_iteration, color);
+      } else {
+        const f3 hn = xyz(nm[j]);
+        if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, hn, tp[j].x);  // path_tracer.cu:308-311
+        const uint32_t ms = __float_as_uint(nm[j].w);
+        const DMaterial m = sc.materials[ms & 0x7fffffffu];
+        // RNG re-seeded from the global slot index, then discard(bounce) (path_tracer.cu:300-301)
+        const uint32_t slot = (slot_base ? *slot_base : 0u) + s;
+        Minstd rng;
+        rng.seed(path_seed(slot, iteration));
+        rng.discard((uint32_t)bounce);
+        const f3 hp = mk3(tp[j].y, tp[j].z, tp[j].w);
+        evaluate_material(ro, rd, tmin_flag, hp, hn, ms >> 31, m, rng, color);
+        if (last_bounce) {
+          accumulate_color(fb.color4, local_pixel, acc_iteration, color);  // capped paths deposit raw throughput
+        } else {
+          surv_mask |= 1u << j;
+          o4[j] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixel | (tmin_flag ? 0x80000000u : 0u)));
+          d4[j] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+          t4[j] = make_float4(color.x, color.y, color.z, 0.0f);
+        }
+      }
+    }
+  }
+
+  // ---- the tile's offset comes in ----
+  if (wave == 0u) {
+    uint32_t excl = 0u;
+    if (tile != 0u) {
+      excl = tile_lookback(tile_desc, tile, epoch);
+      if (threadIdx.x == 0u)
+        __hip_atomic_store(&tile_desc[tile], tag | kDescPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0u) {
+      s_excl = excl;
+      if (tile + 1u == tiles) {  // the last tile knows the frame's total (k_scan's epilogue)
+        counters->live[bounce + 1] = last_bounce ? 0u : excl + agg;
+        counters->rays_total += n;
+        counters->paths[bounce] += n;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- survivors to their stable place: tile offset + sub-blocks before + wavefronts before + lanes before ----
+  uint32_t base = s_excl;
+#pragma unroll
+  for (int j = 0; j < kFuseK; ++j) {
+    uint32_t before = 0u, in_sub = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = s_cnt[j * 4 + w];
+      before += (uint32_t)w < wave ? c : 0u;
+      in_sub += c;
+    }
+    const bool survives = (surv_mask >> j & 1u) != 0u;
+    const uint64_t live = __ballot(survives);
+    if (survives) {
+      const uint32_t dst = base + before + rank_below(live);
+      stnt(&out.o4[dst], o4[j]);
+      stnt(&out.d4[dst], d4[j]);
+      stnt(&out.t4[dst], t4[j]);
+      if (octs) octs[dst] = (uint8_t)((d4[j].x < 0.0f ? 1u : 0u) | (d4[j].y < 0.0f ? 2u : 0u) | (d4[j].z < 0.0f ? 4u : 0u));
+    }
+    base += in_sub;
   }
 }
 
@@ -2219,6 +2523,26 @@ void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHi
   hipLaunchKernelGGL(k_shade, dim3(div_up(max_paths, 256u), bi.count), dim3(256), 0, s, scene, in, out, hits,
                      staged ? 1 : 0, bounce, last_bounce ? 1 : 0, slot_base, chunk_offsets, fb, band, counters, octs, bi);
 }
+void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths in, DPaths out,
+                        DHits hits, uint32_t max_paths, bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
+                        unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb, DBand band,
+                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi)
+{
+  const dim3 grid(div_up(max_paths, kFuseTile) * bi.count), block(256);
+#define PT_FUSED(SPH, FIRST)                                                                                                   \
+  hipLaunchKernelGGL((k_shade_fused<SPH, FIRST>), grid, block, 0, s, scene, obj_begin, obj_end, in, out, hits, staged ? 1 : 0, \
+                     bounce, last_bounce ? 1 : 0, slot_base, tile_desc, tile_stride, epoch, fb, band, counters, octs, bi)
+  if (obj_begin < obj_end) {
+    if (first) PT_FUSED(true, true);
+    else PT_FUSED(true, false);
+  } else if (first) {
+    PT_FUSED(false, true);   // a scene without objects: every ray misses
+  } else {
+    PT_FUSED(false, false);  // (some closest-hit launch has written every record of the bounce)
+  }
+#undef PT_FUSED
+}
+uint32_t shade_tiles_per_frame(uint32_t max_paths) { return div_up(max_paths, kFuseTile); }
 void launch_sort_octant(hipStream_t s, const uint8_t* octs, uint32_t* order, uint32_t max_paths, int bounce,
                         DeviceCounters* counters, const DBatchInfo& bi)
 {

@@ -77,8 +77,11 @@ struct ptc_ctx {
     bool own_stream = false;
     DPaths paths[2]{};
     DHits hits{};
-    uint32_t* chunk_counts = nullptr;
+    uint32_t* chunk_counts = nullptr;   // "fused_shade" 0: k_tail_count -> k_scan -> k_shade
     uint32_t* chunk_offsets = nullptr;
+    unsigned long long* tile_desc = nullptr;  // k_shade_fused: look-back descriptors, tile_stride per frame of the batch
+    uint32_t tile_stride = 0;
+    uint32_t shade_epoch = 0;           // launches of k_shade_fused on these descriptors so far (1 .. 2^30 - 1, then round again)
     uint32_t* slow_list = nullptr;  // slots of rays set aside for the exact redo at the end of a traversal launch
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
@@ -176,6 +179,7 @@ struct ptc_ctx {
   // never waits for them, they only size the traversal launches
   uint32_t est_live[kMaxBounces + 1] = {};
   bool est_valid = false;
+  bool fused_shade = true;    // "fused_shade": the end of a bounce in one pass (k_shade_fused); 0: k_tail_count -> k_scan -> k_shade
   int ray_sort = 0;           // "ray_sort": 1 = traversal lanes pick their rays up grouped by direction octant (bounces >= 1)
   int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2
   uint32_t lds_entries = kLds4;  // the kernels' LDS stack (pt_device.hpp); fewer only through "debug_lds_entries"
@@ -928,6 +932,10 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, (size_t)B * chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, (size_t)B * chunks)) return rc;
+    sl.tile_stride = shade_tiles_per_frame((uint32_t)P);
+    if (int rc = dev_alloc(ctx, pool, &sl.tile_desc, (size_t)B * sl.tile_stride)) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(sl.tile_desc, 0, sizeof(unsigned long long) * (size_t)B * sl.tile_stride, ctx->stream));
+    sl.shade_epoch = 0;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_stack, (size_t)kStackDepth * kWave)) return rc;
     if (ctx->ray_sort) {
@@ -1084,6 +1092,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (std::strcmp(name, "layout_on_device") == 0) {
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "layout_on_device must be 0 or 1");
     ctx->layout_on_device = value != 0;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "fused_shade") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "fused_shade must be 0 or 1");
+    ctx->fused_shade = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "merge_instances") == 0) {
@@ -1300,11 +1313,20 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   }
   // the sphere run that ends the object list (variant 3 only) + the live counts; their scan
   const bool tail = persistent && ctx->tail_begin < ctx->tail_end;
-  launch_tail_count(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, sl.hits, ctx->pix_count,
-                    bounce, sl.chunk_counts, sl.counters, sl.bi);
-  launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
-  launch_shade(sl.stream, scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
-               sl.chunk_offsets, sl.stage, ctx->band, sl.counters, ctx->ray_sort && !last ? sl.octs : nullptr, sl.bi);
+  uint8_t* octs = ctx->ray_sort && !last ? sl.octs : nullptr;
+  if (ctx->fused_shade) {
+    // one pass: trailing spheres + material + stable compaction (decoupled look-back) + final gather
+    sl.shade_epoch = sl.shade_epoch >= 0x3fffffffu ? 1u : sl.shade_epoch + 1u;
+    launch_shade_fused(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, out, sl.hits, ctx->pix_count,
+                       ctx->staging(), bounce, last, slot_base_dev, sl.tile_desc, sl.tile_stride, sl.shade_epoch, sl.stage, ctx->band,
+                       sl.counters, octs, sl.bi);
+  } else {
+    launch_tail_count(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, sl.hits, ctx->pix_count,
+                      bounce, sl.chunk_counts, sl.counters, sl.bi);
+    launch_scan(sl.stream, bounce, last, sl.chunk_counts, sl.chunk_offsets, sl.counters, sl.bi);
+    launch_shade(sl.stream, scene, in, out, sl.hits, ctx->pix_count, ctx->staging(), bounce, last, slot_base_dev,
+                 sl.chunk_offsets, sl.stage, ctx->band, sl.counters, octs, sl.bi);
+  }
   sl.cur ^= 1;
   sl.bounces_done = bounce + 1;
   return check_last(ctx, "bounce");

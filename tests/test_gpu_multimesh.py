@@ -247,7 +247,7 @@ def test_intersect_rays_with_many_mesh_objects(pkg):
     count = 150
     for k in range(count):
         x, y = (k % 15) - 7.0, (k // 15) - 4.5
-        sc.add_object(mesh, glm.compose([glm.scale(0.35), glm.translate((x, y, 0.0))]), "last" if k >= 128 else "first")
+        sc.add_object(mesh, glm.compose([glm.scale(0.9), glm.translate((x, y, 0.0))]), "last" if k >= 128 else "first")
     sc.add_object(pkg.Sphere((0, 0, 0), 0.2), glm.translate((0.0, 0.0, 2.0)), "first")   # a sphere run behind them all
     flat = sc.build_scene()
     rng = np.random.default_rng(11)
