@@ -23,17 +23,8 @@ constexpr int kWorkSlots = 4;
 // Traversal stack entries per lane the four-wide walk keeps in LDS (6 KiB per wavefront at 24); deeper entries go to
 // DScene::spill.  ONE constant for the kernels' LDS arrays and the host's DScene::lds_cap / spill sizing: a build with
 // -DPT_T4_LDS=16 against a host that assumed 24 wrote past its stack (round-2 A/B fault).
-// PT_QUAD_FETCH: the four lanes of a quad fetch the four quarters of ONE 64-byte record per load instruction, straight
-// into LDS (k_traverse4, see there); its 4 KiB record image per wavefront is paid for with stack entries.
-#ifndef PT_QUAD_FETCH
-#define PT_QUAD_FETCH 1
-#endif
 #ifndef PT_T4_LDS
-#if PT_QUAD_FETCH
-#define PT_T4_LDS 10
-#else
 #define PT_T4_LDS 24
-#endif
 #endif
 constexpr int kLds4 = PT_T4_LDS;
 static_assert(kLds4 >= 4 && kLds4 <= kStackDepth, "PT_T4_LDS out of range");

@@ -951,20 +951,6 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   // explicitly an LDS pointer: as a generic pointer the pop below compiles to a flat load
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   lds_u32* stack = (lds_u32*)s_stack + threadIdx.x;
-#if PT_QUAD_FETCH
-  // Record image of the quad-cooperative fetch (see the loop): load instruction k puts lane L's 16 bytes at
-  // s_img[k * 64 + L] (LDS-DMA writes base + lane * 16), i.e. quarter-position m = L & 3 of the record owned by lane
-  // 4 * (L >> 2) + k.  Owner lane r = 4 Q + k therefore finds its record at s_img[k * 64 + 4 Q ..+3]; the quarters sit
-  // rotated by k inside it (position p holds quarter (p - k) & 3 -- the fetching lanes rotate their SOURCE address), so
-  // that the sixteen lanes of a ds_read_b128 pass, which read the same quarter j of sixteen records, hit sixteen
-  // different bank groups: lane r reads position (j + k) & 3.
-  static_assert(kTriVec4 == 4u, "the quad fetch reads 64-byte records");
-  typedef uint32_t img_u32x4 __attribute__((ext_vector_type(4)));
-  __shared__ img_u32x4 s_img[4 * kWave];
-  typedef __attribute__((address_space(3))) img_u32x4 lds_u4;
-  const uint32_t quad_m = threadIdx.x & 3u;
-  const lds_u4* my_rec = (const lds_u4*)s_img + quad_m * 64u + (threadIdx.x & ~3u);
-#endif
   const uint32_t gid = blockIdx.x * kWave + threadIdx.x;
   // `slot` below is batch-global (frame * bi.stride + slot in the frame); flags, the slow-ray list and the
   // test tallies of the whole batch go to frame 0's counters
@@ -1275,50 +1261,6 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     // lane falls back to is read from LDS meanwhile.  Vector-memory instructions and dependent round trips are
     // what this loop is bound by (lesson x): four loads and one wait per iteration, where
     // separate node and triangle phases needed seven loads and two waits.
-#if PT_QUAD_FETCH
-    // Quad-cooperative fetch.  A lane's step needs one 64-byte record (node or triangle) from an address of its own.
-    // Fetched by the lane itself that is four 16-byte loads to one line: the L1's address path (one tag lookup per
-    // distinct line and instruction) saw 36 lookups per instruction, 144 per iteration, and was the busiest unit of the
-    // kernel.  Here load instruction k serves the records of lanes 4 Q + k: the four lanes of quad Q
-    // fetch its four quarters -- one lookup per quad, 16 per instruction, 64 per iteration -- and the data goes straight
-    // to LDS (global_load_lds_dwordx4: no VGPR destination, no transpose in registers); every lane then reads its own
-    // record back with four conflict-free ds_read_b128.  All 64 lanes take part whatever their own state (an idle lane
-    // fetches for its quad and owns a dummy record).
-    const bool is_leaf = (cur & kLeafBit) != 0u;
-    const uint32_t index = cur & ~kLeafBit;
-    uint4 q0, q1, q2, q3;
-    uint32_t below;
-    {
-      const char* rec = !active ? reinterpret_cast<const char*>(tris)
-                        : is_leaf ? reinterpret_cast<const char*>(tris) + 64u * (size_t)index
-                                  : reinterpret_cast<const char*>(sc.cur.bvh4q) + 64u * (size_t)index;
-      const uint32_t lo = (uint32_t)(uintptr_t)rec, hi = (uint32_t)((uintptr_t)rec >> 32);
-      typedef __attribute__((address_space(1))) const void gptr_t;
-      typedef __attribute__((address_space(3))) void lptr_t;
-#define PT_QUAD_LOAD(k)                                                                                                     \
-  {                                                                                                                         \
-    const uint32_t alo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, (k) * 0x55, 0xf, 0xf, false);                   \
-    const uint32_t ahi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, (k) * 0x55, 0xf, 0xf, false);                   \
-    const uint64_t src = (((uint64_t)ahi << 32) | alo) + (uint64_t)(((quad_m - (k)) & 3u) << 4);                           \
-    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)((lds_u4*)s_img + (k) * 64), 16, 0, 0);                         \
-  }
-      PT_QUAD_LOAD(0)
-      PT_QUAD_LOAD(1)
-      PT_QUAD_LOAD(2)
-      PT_QUAD_LOAD(3)
-#undef PT_QUAD_LOAD
-      below = peek();
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the four pieces are in LDS
-      asm volatile("" ::: "memory");
-      const img_u32x4 w0 = my_rec[(0u + quad_m) & 3u], w1 = my_rec[(1u + quad_m) & 3u];
-      const img_u32x4 w2 = my_rec[(2u + quad_m) & 3u], w3 = my_rec[(3u + quad_m) & 3u];
-      q0 = make_uint4(w0.x, w0.y, w0.z, w0.w);
-      q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
-      q2 = make_uint4(w2.x, w2.y, w2.z, w2.w);
-      q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
-    }
-    if (active) {
-#else
     if (active) {
       const bool is_leaf = (cur & kLeafBit) != 0u;
       const uint32_t index = cur & ~kLeafBit;
@@ -1351,7 +1293,6 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));  // ... and nothing reads them above this line
       const uint4 q0 = make_uint4(w0.x, w0.y, w0.z, w0.w), q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
       const uint4 q2 = make_uint4(w2.x, w2.y, w2.z, w2.w), q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
-#endif
       if (!is_leaf) {
         if (kCount) ++tally.nodes;
         // 64-byte node: origin + power-of-two grid steps + 8-bit plane coordinates (Wide4Accel::nodes_q).  A plane
