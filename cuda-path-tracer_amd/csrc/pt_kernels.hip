@@ -1700,15 +1700,21 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 //     its paths survive -- so the tile's survivor count is published after ONE round trip to memory;
 //   * the stable offset of the tile = survivors of all tiles before it, found by decoupled look-back over the tile
 //     descriptors (aggregate / inclusive prefix, Merrill & Garland): a wavefront reads up to 64 predecessors at once;
-//   * tiles are taken in TICKET order (one atomic per workgroup on the frame's counter line), not blockIdx order: a
-//     workgroup that waits for a predecessor's descriptor knows that predecessor is running or done, whatever else
-//     (the other stream's persistent traversal wavefronts) holds the chip's wavefront slots.  Blocks are numbered
-//     frame-fastest, so consecutive tickets of a batch go to different frames' counter lines;
+//   * tile = blockIdx / frames (blocks are numbered frame-fastest).  A workgroup that waits for a predecessor's descriptor
+//     relies on that predecessor having been dispatched: workgroups of a grid are handed out in ascending order (each
+//     XCD takes its share in order; the slots a later workgroup could block are never the ones an earlier one of the
+//     same XCD is waiting for, and the other stream's persistent traversal wavefronts leave on their own).  HIP does
+//     not promise that order, so the wait is BOUNDED: a workgroup that has waited about a second sets
+//     kFlagDispatchOrder and gives up -- ptc_get_stats then reports an error instead of an image (never seen in any
+//     run; "fused_shade" 0 selects the three-kernel path, which has no wait between workgroups).  Taking the tiles by
+//     ticket instead (one atomic per workgroup, the textbook way) was measured: the atomic's round trip sits in front
+//     of every workgroup's first load and cost 3 % of the whole frame (profiles/r03_fused_shade_ab.txt);
 //   * descriptors carry the launch's epoch, so nothing has to be cleared between launches.
 // Same arithmetic and same slot order as the three kernels it replaces: images are bit-identical (tests).
 #ifndef PT_FUSE_K
 #define PT_FUSE_K 4
 #endif
+
 constexpr int kFuseK = PT_FUSE_K;
 constexpr uint32_t kFuseTile = 256u * kFuseK;
 constexpr unsigned long long kDescAggregate = 1ull << 32, kDescPrefix = 2ull << 32;
@@ -1721,11 +1727,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // exclusive prefix of `tile` (survivors of tiles [0, tile)), by the calling wavefront; every lane returns it
-__device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc, uint32_t tile, uint32_t epoch)
+__device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc, uint32_t tile, uint32_t epoch, uint32_t* flags)
 {
   uint32_t excl = 0u;
   const int lane = (int)lane_id();
   int pos = (int)tile - 1;
+  uint32_t spins = 0u;
   while (pos >= 0) {
     const int idx = pos - lane;  // lane 0 = the nearest predecessor
     for (;;) {
@@ -1744,6 +1751,10 @@ __device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc
         break;  // 64 aggregates and no prefix among them: look further back
       }
       __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 20)) {  // (about a second) a predecessor that never ran: see the kernel's header
+        if (lane == 0) atomicOr(flags, kFlagDispatchOrder);
+        return excl;
+      }
     }
     pos -= kWave;
   }
@@ -1756,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_shade_fused(DScene sc, uint32_t obj_beg
                                                      unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb,
                                                      DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi)
 {
-  __shared__ uint32_t s_tile, s_excl;
+  __shared__ uint32_t s_excl;
   __shared__ uint32_t s_cnt[kFuseK * 4];
   const uint32_t frame = blockIdx.x % bi.count;  // frame-fastest: neighbouring blocks take their tickets on different lines
   const uint32_t iteration = bi.iteration[frame];
@@ -1779,15 +1790,7 @@ __global__ __launch_bounds__(256) void k_shade_fused(DScene sc, uint32_t obj_beg
   counters += frame;
   const uint32_t n = counters->live[bounce];
   const uint32_t tiles = (n + kFuseTile - 1u) / kFuseTile;
-  const uint32_t blocks_per_frame = gridDim.x / bi.count;
-  if (threadIdx.x == 0u) {
-    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every workgroup of the frame has its ticket once the last one is out: the next launch starts from zero
-    if (t + 1u == blocks_per_frame) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_tile = t;
-  }
-  __syncthreads();
-  const uint32_t tile = s_tile;
+  const uint32_t tile = blockIdx.x / bi.count;
   if (tile >= tiles) {
     if (tiles == 0u && tile == 0u && threadIdx.x == 0u) counters->live[bounce + 1] = 0u;  // nothing alive: nothing follows
     return;
@@ -1895,7 +1898,7 @@ __global__ __launch_bounds__(256) void k_shade_fused(DScene sc, uint32_t obj_beg
   if (wave == 0u) {
     uint32_t excl = 0u;
     if (tile != 0u) {
-      excl = tile_lookback(tile_desc, tile, epoch);
+      excl = tile_lookback(tile_desc, tile, epoch, &counters->flags);
       if (threadIdx.x == 0u)
         __hip_atomic_store(&tile_desc[tile], tag | kDescPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1989,11 +1992,41 @@ __global__ __launch_bounds__(256) void k_accumulate(DFrame stage, DFrame fb, uin
 {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= pix_count) return;
-  for (uint32_t f = 0; f < bi.count; ++f) {
-    const float4 c = ldnt(&stage.color4[(size_t)f * bi.stride + i]), g = ldnt(&stage.nd4[(size_t)f * bi.stride + i]);
-    accumulate_color(fb.color4, i, bi.iteration[f], mk3(c.x, c.y, c.z));
-    accumulate_nd(fb.nd4, i, bi.iteration[f], mk3(g.x, g.y, g.z), g.w);
+  // The running means of a pixel stay in registers over the frames of the batch (one read and one write of the
+  // framebuffer per batch; the same operations in the same order as a fold frame by frame), and the staged samples are
+  // requested eight frames at a time: one after the other, a thread of a 32-frame batch sat through 32 dependent round
+  // trips and the kernel moved 2.3 TB/s.
+  const uint32_t first = bi.iteration[0];
+  float4 col = make_float4(0.f, 0.f, 0.f, 0.f), nd = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (first != 0u) {
+    col = ldnt(&fb.color4[i]);
+    nd = ldnt(&fb.nd4[i]);
   }
+  constexpr uint32_t kAhead = 8u;
+  for (uint32_t f0 = 0; f0 < bi.count; f0 += kAhead) {
+    float4 c[kAhead], g[kAhead];
+#pragma unroll
+    for (uint32_t k = 0; k < kAhead; ++k) {
+      const uint32_t f = min(f0 + k, bi.count - 1u);
+      c[k] = ldnt(&stage.color4[(size_t)f * bi.stride + i]);
+      g[k] = ldnt(&stage.nd4[(size_t)f * bi.stride + i]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kAhead; ++k) {
+      if (f0 + k >= bi.count) break;
+      const uint32_t it = bi.iteration[f0 + k];
+      col.x = running_mean(it, col.x, c[k].x);
+      col.y = running_mean(it, col.y, c[k].y);
+      col.z = running_mean(it, col.z, c[k].z);
+      nd.x = running_mean(it, nd.x, g[k].x);
+      nd.y = running_mean(it, nd.y, g[k].y);
+      nd.z = running_mean(it, nd.z, g[k].z);
+      nd.w = running_mean(it, nd.w, g[k].w);
+    }
+  }
+  col.w = 0.0f;
+  stnt(&fb.color4[i], col);
+  stnt(&fb.nd4[i], nd);
 }
 
 // path_tracing_mega_kernel, path_tracer.cu:227-269: the whole path in one thread, one RNG stream per

@@ -62,6 +62,10 @@ def test_every_schedule_matches_reference_order_and_oracle(pkg, orc, small_scene
     for fif, batch in ((1, 1), (6, 3)):
         got = frames(pkg, scene, flat, w, h, 3, 8, fif=fif, params=(("batch_frames", batch), ("ray_sort", 1)))
         assert same(got, base), ("ray_sort", fif, batch)
+    # the end of a bounce as three kernels (count, scan, shade) instead of the one-pass kernel with its look-back
+    for fif, batch in ((1, 1), (6, 3)):
+        got = frames(pkg, scene, flat, w, h, 3, 8, fif=fif, params=(("batch_frames", batch), ("fused_shade", 0)))
+        assert same(got, base), ("three-kernel shade", fif, batch)
     # the default walk with only two stack entries per lane in LDS: everything deeper goes through the global
     # overflow area (push, peek and pop on both sides of the boundary)
     for fif, batch in ((1, 1), (6, 3)):
@@ -294,6 +298,7 @@ def test_benchmark_size_against_reference_order(pkg, big):
     # walk overflows into the per-slot global area on this tree, concurrently in every launch
     got4 = frames(pkg, scene, flat, 1920, 1080, 10, 8, fif=10, params=(("batch_frames", 1), ("debug_lds_entries", 4)))
     assert same(got4, base)
+    assert same(frames(pkg, scene, flat, 1920, 1080, 10, 8, params=(("fused_shade", 0),)), base)
     live = got["stats"]["last_live"]
     assert live[0] == 1920 * 1080 and all(a >= b for a, b in zip(live, live[1:]))
     assert np.isfinite(got["color"]).all() and 0.0 <= got["color"].min() and got["color"].max() <= 1.0 + 1e-6
