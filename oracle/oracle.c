@@ -700,27 +700,41 @@ static void ostack_push(OStack* s, uint32_t v)
   s->data[s->size++] = v;
 }
 
-/* path_tracer.cu:36-76 */
+/* path_tracer.cu:36-76.  The arrays of "the" mesh: the whole scene arrays in the reference's one-mesh scene, the
+ * object's slice of them when the scene has a mesh table (OScene::meshes; extension, see oracle.h). */
 static int ray_mesh(ORay ray, const OScene* scene, const OObject* obj, OIntersection* record, OStack* stack)
 {
   int hit = 0;
   ORay transformed_ray;
   orc_inverse_transform_ray(&obj->m, &obj->inv_m, &ray, &transformed_ray);
 
+  const float* positions = scene->positions;
+  const uint32_t* indices = scene->indices;
+  const OBVHNode* bvh = scene->bvh;
+  uint32_t bvh_node_count = scene->bvh_node_count;
+  if (scene->meshes) {
+    if (obj->index >= scene->mesh_count) return 0;
+    const struct OMeshRange* r = &scene->meshes[obj->index];
+    positions += 3u * (size_t)r->first_vertex;
+    indices += r->first_index;
+    bvh += r->first_bvh_node;
+    bvh_node_count = r->bvh_node_count;
+  }
+
   stack->size = 0;
-  if (scene->bvh_node_count == 0) return 0; /* empty mesh: the reference panics at build time */
+  if (bvh_node_count == 0) return 0; /* empty mesh: the reference panics at build time */
   ostack_push(stack, 0);
   while (stack->size != 0) {
     const uint32_t node_index = stack->data[--stack->size];
-    const OBVHNode node = scene->bvh[node_index];
+    const OBVHNode node = bvh[node_index];
     if (node.primitive_count != 0) {
       const uint32_t i = node.first_child_or_primitive;
-      const uint32_t index0 = scene->indices[i];
-      const uint32_t index1 = scene->indices[i + 1];
-      const uint32_t index2 = scene->indices[i + 2];
-      const ovec3 p0 = transform_point(&obj->m, vload(scene->positions + 3u * (size_t)index0));
-      const ovec3 p1 = transform_point(&obj->m, vload(scene->positions + 3u * (size_t)index1));
-      const ovec3 p2 = transform_point(&obj->m, vload(scene->positions + 3u * (size_t)index2));
+      const uint32_t index0 = indices[i];
+      const uint32_t index1 = indices[i + 1];
+      const uint32_t index2 = indices[i + 2];
+      const ovec3 p0 = transform_point(&obj->m, vload(positions + 3u * (size_t)index0));
+      const ovec3 p1 = transform_point(&obj->m, vload(positions + 3u * (size_t)index1));
+      const ovec3 p2 = transform_point(&obj->m, vload(positions + 3u * (size_t)index2));
       if (ray_triangle(&ray, p0, p1, p2, record)) {
         hit = 1;
         ray.t_max = record->t;

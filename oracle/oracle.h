@@ -64,6 +64,7 @@ typedef struct { int32_t type; float p[4]; } OMaterial;
 typedef struct { OAABB aabb; uint32_t first_child_or_primitive; uint32_t primitive_count; } OBVHNode;
 
 /* The flat arrays SceneDescription::build_scene uploads (scene_description.cpp:12-117) */
+struct OMeshRange;
 typedef struct {
   const OObject* objects;
   uint32_t object_count;
@@ -78,7 +79,15 @@ typedef struct {
   uint32_t index_count;
   const OBVHNode* bvh;
   uint32_t bvh_node_count;
+  /* Optional mesh table (NULL / 0 = the reference: ONE mesh per scene, every mesh object instantiates it whatever its
+   * `index` says, scene_description.cpp:42,95).  With a table, a mesh object's `index` names its mesh: ranges into the
+   * concatenated positions / indices / bvh arrays, each mesh as bvh_from_mesh sees it on its own (vertex indices and
+   * child indices relative to the mesh's own first vertex / first node).  This extends the reference's rule, it does
+   * not restate anything the reference does: results with a table are PARITY UNPINNED by construction. */
+  const struct OMeshRange* meshes;
+  uint32_t mesh_count;
 } OScene;
+struct OMeshRange { uint32_t first_vertex, vertex_count, first_index, index_count, first_bvh_node, bvh_node_count; };
 
 /* src/lib/camera.hpp:17-23 */
 typedef struct { float position[3]; float rotation_wxyz[4]; float vfov; } OCamera;

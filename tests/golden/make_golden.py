@@ -29,6 +29,70 @@ def golden_scenes():
     }
 
 
+def multimesh_scenes():
+    """Scenes with SEVERAL distinct meshes (ptc_mesh_range / OScene::meshes; the reference keeps one mesh per scene,
+    scene_description.cpp:42,95, so these pin the extension, not the reference): name -> (SceneDescription, w, h, max_bounces)."""
+    glm = pkg.glmlite
+    two = pkg.scenes.cornell_spheres((48, 32))            # walls and three small spheres
+    a = pkg.scenes.displaced_sphere_mesh(16, 32)
+    b = pkg.scenes.heightfield_mesh(33, 17, 2.0, 1.0, seed=4)
+    two.add_mesh("a", a)
+    two.add_mesh("b", b)
+    two.add_material("ma", pkg.DiffuseMateral((0.8, 0.3, 0.2)))
+    two.add_material("mb", pkg.MetalMaterial((0.7, 0.7, 0.9), 0.1))
+    two.add_object(a, glm.compose([glm.scale(0.5), glm.translate((-0.7, 0.2, 0.4))]), "ma")
+    two.add_object(b, glm.compose([glm.rotate(np.float32(0.4), (0.0, 1.0, 0.0)), glm.translate((0.2, -0.9, 0.0))]), "mb")
+    two.add_object(a, glm.compose([glm.rotate(np.float32(0.6), (0.3, 1.0, 0.2)), glm.scale((0.4, 0.25, 0.5)),
+                                   glm.translate((0.8, 0.5, -0.3))]), "mb")
+    # three meshes, two of them placed exactly on top of each other (every hit there is a t == t_max tie, won by the
+    # later object), a glass mesh, a sphere between the mesh objects
+    ties = pkg.SceneDescription()
+    ties.resolution = (40, 40)
+    ties.camera = pkg.Camera(position=(0.0, 0.3, 3.2), rotation=(1.0, 0.0, 0.0, 0.0), vfov=float(np.radians(45)))
+    c = pkg.scenes.displaced_sphere_mesh(10, 20)
+    d = pkg.scenes.heightfield_mesh(17, 9, 3.0, 2.0, seed=9)
+    e = pkg.scenes.displaced_sphere_mesh(6, 12)
+    for name, mat in (("red", pkg.DiffuseMateral((0.8, 0.2, 0.2))), ("grey", pkg.DiffuseMateral((0.6, 0.6, 0.6))),
+                      ("steel", pkg.MetalMaterial((0.8, 0.8, 0.85), 0.05)), ("glass", pkg.DielectricMaterial(1.5))):
+        ties.add_material(name, mat)
+    for name, mesh in (("c", c), ("d", d), ("e", e)):
+        ties.add_mesh(name, mesh)
+    place = glm.compose([glm.scale(0.6), glm.translate((-0.5, 0.3, 0.0))])
+    ties.add_object(c, place, "red")
+    ties.add_object(d, glm.translate((0.0, -0.6, 0.0)), "grey")
+    ties.add_object(pkg.Sphere((0, 0, 0), 0.3), glm.translate((0.6, 0.0, 0.6)), "steel")
+    ties.add_object(c, place, "steel")                    # coincident with the first object: wins every tie
+    ties.add_object(e, glm.compose([glm.scale(0.5), glm.translate((0.5, 0.5, -0.2))]), "glass")
+    return {"two_meshes": (two, 48, 32, 6), "three_meshes_ties": (ties, 40, 40, 8)}
+
+
+def main_multimesh():
+    out = {}
+    rng = np.random.default_rng(21)
+    for name, (scene, w, h, mb) in multimesh_scenes().items():
+        flat = scene.build_scene(distinct_meshes=True)
+        r = orc.render_streaming(flat, scene.camera, w, h, 0, 3, mb)
+        for k in ("color", "normal", "depth", "live"):
+            out[f"{name}_{k}"] = r[k]
+        out[f"{name}_rays"] = np.array([r["rays"]], dtype=np.uint64)
+        n = 1500
+        origin = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+        target = rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32)
+        dirs = target - origin
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        rays = np.zeros((n, 8), dtype=np.float32)
+        rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = origin, 1e-4, dirs, np.finfo(np.float32).max
+        recs, hit = orc.intersect_rays(flat, rays)
+        out[f"{name}_probe_rays"] = rays
+        out[f"{name}_probe_hit"] = hit
+        out[f"{name}_probe_t"] = recs["t"]
+        out[f"{name}_probe_normal"] = recs["normal"]
+        out[f"{name}_probe_material"] = recs["material_id"].astype(np.uint32)
+        out[f"{name}_probe_side"] = recs["side"]
+    np.savez_compressed(os.path.join(HERE, "multimesh.npz"), **out)
+    print("wrote", os.path.join(HERE, "multimesh.npz"))
+
+
 def main():
     out = {}
     for name, (scene, w, h) in golden_scenes().items():
@@ -85,4 +149,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["multimesh"]:     # only the multi-mesh fixtures (the others stay as committed)
+        main_multimesh()
+    else:
+        main()
+        main_multimesh()

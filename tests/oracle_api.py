@@ -17,7 +17,8 @@ class OScene(C.Structure):
     _fields_ = [("objects", C.c_void_p), ("object_count", C.c_uint32), ("object_material_indices", C.c_void_p),
                 ("spheres", C.c_void_p), ("sphere_count", C.c_uint32), ("materials", C.c_void_p),
                 ("material_count", C.c_uint32), ("positions", C.c_void_p), ("vertex_count", C.c_uint32),
-                ("indices", C.c_void_p), ("index_count", C.c_uint32), ("bvh", C.c_void_p), ("bvh_node_count", C.c_uint32)]
+                ("indices", C.c_void_p), ("index_count", C.c_uint32), ("bvh", C.c_void_p), ("bvh_node_count", C.c_uint32),
+                ("meshes", C.c_void_p), ("mesh_count", C.c_uint32)]
 
 
 class OCamera(C.Structure):
@@ -144,7 +145,27 @@ class SceneHandle:
     def __init__(self, flat):
         self.flat = flat
         bvh = flat.bvh
-        if bvh is None and len(flat.indices):
+        self.mesh_ranges = None
+        ranges = getattr(flat, "mesh_ranges", None)
+        if ranges is not None:
+            # a scene with a mesh table (extension, oracle.h): every mesh gets its own reference BVH (orc_bvh_build on
+            # its slice, as bvh_from_mesh sees it), concatenated; the table says where each one starts
+            ranges = np.array(ranges, dtype=np.uint32).reshape(-1, 6)
+            positions = np.ascontiguousarray(flat.positions, dtype=np.float32).reshape(-1, 3)
+            trees, depth, first = [], 0, 0
+            for r in ranges:
+                if r[3] == 0:
+                    r[4], r[5] = first, 0
+                    continue
+                nodes, d = build_bvh(positions[r[0]:r[0] + r[1]], flat.indices[r[2]:r[2] + r[3]])
+                r[4], r[5] = first, len(nodes)
+                first += len(nodes)
+                depth = max(depth, d)
+                trees.append(nodes)
+            bvh = np.concatenate(trees) if trees else None
+            self.depth = depth
+            self.mesh_ranges = np.ascontiguousarray(ranges)
+        elif bvh is None and len(flat.indices):
             bvh, self.depth = build_bvh(flat.positions, flat.indices)
         self.bvh = bvh
         s = OScene()
@@ -161,6 +182,8 @@ class SceneHandle:
         s.index_count = len(flat.indices)
         s.bvh = _p(bvh) if bvh is not None else None
         s.bvh_node_count = len(bvh) if bvh is not None else 0
+        s.meshes = _p(self.mesh_ranges) if self.mesh_ranges is not None else None
+        s.mesh_count = len(self.mesh_ranges) if self.mesh_ranges is not None else 0
         self.c = s
 
 

@@ -269,3 +269,95 @@ def test_intersect_rays_with_many_mesh_objects(pkg):
     assert np.array_equal(got[0], want[0])
     for k in (1, 2, 3):
         assert np.array_equal(got[k][hit], want[k][hit]), k
+
+
+def _golden_multimesh(golden_dir):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.multimesh_scenes(), np.load(os.path.join(golden_dir, "multimesh.npz"))
+
+
+@pytest.mark.parametrize("name", ["two_meshes", "three_meshes_ties"])
+def test_multimesh_frames_and_rays_against_the_oracle(pkg, orc, golden_dir, name):
+    """Round 2 checked multi-mesh scenes only against the HIP path itself (the oracle had no mesh table).  Now: frames
+    of every schedule == the oracle's frames (tests/golden/multimesh.npz, regenerated by tests/test_oracle_multimesh.py
+    on the CPU) bit for bit, and ptc_intersect_rays == orc.intersect_rays on the committed probe rays."""
+    scenes, golden = _golden_multimesh(golden_dir)
+    scene, w, h, mb = scenes[name]
+    flat = scene.build_scene(distinct_meshes=True)
+    for variant, params in ((3, ()), (3, (("frames_in_flight", 6), ("batch_frames", 3))), (3, (("merge_instances", 0),)),
+                            (3, (("fused_shade", 0),)), (3, (("layout_on_device", 0), ("bvh_build_on_device", 0))), (1, ()), (0, ())):
+        with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+            for k, v in params:
+                pt.set_param(k, v)
+            pt.create_buffers((w, h), flat)
+            pt.set_trace_variant(variant)
+            pt.max_iterations = 3
+            for _ in range(3):
+                pt.path_trace(scene.camera)
+            for k in ("color", "normal", "depth"):
+                assert np.array_equal(pt.download(k), golden[f"{name}_{k}"]), (variant, params, k)
+            st = pt.stats()
+            assert st["rays_total"] == int(golden[f"{name}_rays"][0]), (variant, params)
+            assert st["last_live"][:mb] == [int(v) for v in golden[f"{name}_live"][-1]], (variant, params)
+    rays = golden[f"{name}_probe_rays"]
+    m = golden[f"{name}_probe_hit"].astype(bool)
+    with pkg.PathTracer() as pt:
+        pt.create_buffers((32, 32), flat)
+        for variant in (3, 1, 0):
+            pt.set_trace_variant(variant)
+            t, nrm, mat, side = pt.intersect_rays(rays)
+            assert np.array_equal(t >= 0, m), variant
+            assert np.array_equal(t[m], golden[f"{name}_probe_t"][m]) and np.array_equal(nrm[m], golden[f"{name}_probe_normal"][m]), variant
+            assert np.array_equal(mat[m], golden[f"{name}_probe_material"][m]) and np.array_equal(side[m], golden[f"{name}_probe_side"][m]), variant
+    # and against a fresh oracle run (the fixture is not stale)
+    ref = orc.render_streaming(flat, scene.camera, w, h, 0, 3, mb)
+    assert np.array_equal(ref["color"], golden[f"{name}_color"])
+
+
+def test_run_of_instances_against_the_oracle(pkg, orc):
+    """the five-instance scene of test_run_of_instances_in_one_launch (ONE launch per bounce walks all five: k_traverse4m)
+    against the oracle itself: frames, and 80,000 rays one by one"""
+    glm = pkg.glmlite
+    a = pkg.scenes.displaced_sphere_mesh(16, 32)
+    t0 = glm.compose([glm.scale(0.5), glm.translate((-0.7, 0.2, 0.4))])
+    placements = [t0, glm.compose([glm.scale(0.5), glm.translate((-0.55, 0.25, 0.4))]), t0,
+                  glm.compose([glm.rotate(np.float32(0.6), (0.3, 1.0, 0.2)), glm.scale((0.4, 0.25, 0.5)), glm.translate((0.8, 0.5, -0.3))]),
+                  glm.compose([glm.scale(0.3), glm.translate((0.1, -0.4, 0.9))])]
+    sc = pkg.SceneDescription()
+    sc.add_mesh("a", a)
+    for k, tr in enumerate(placements):
+        sc.add_material(f"m{k}", pkg.DiffuseMateral((0.15 * (k + 1), 0.5, 0.5)))
+        sc.add_object(a, tr, f"m{k}")
+    flat = sc.build_scene()
+    cam = pkg.Camera(position=(0.0, 0.0, 4.0), vfov=0.8)
+    ref = orc.render_streaming(flat, cam, 128, 96, 0, 3, 5)
+    for params in ((), (("merge_instances", 0),), (("frames_in_flight", 6), ("batch_frames", 3))):
+        with pkg.PathTracer(device=0, max_bounces=5) as pt:
+            for k, v in params:
+                pt.set_param(k, v)
+            pt.create_buffers((128, 96), flat)
+            for _ in range(3):
+                pt.path_trace(cam)
+            for k in ("color", "normal", "depth"):
+                assert np.array_equal(pt.download(k), ref[k]), (params, k)
+            assert pt.stats()["rays_total"] == ref["rays"]
+    rng = np.random.default_rng(9)
+    n = 80_000
+    origin = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+    d = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32) - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 20] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 20)] * rng.choice([-1.0, 1.0], (n // 20, 1)).astype(np.float32)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = origin; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.finfo(np.float32).max
+    recs, hit = orc.intersect_rays(flat, rays)
+    m = hit.astype(bool)
+    with pkg.PathTracer() as pt:
+        pt.create_buffers((32, 32), flat)
+        t, nrm, mat, side = pt.intersect_rays(rays)
+    assert np.array_equal(t >= 0, m) and 0.05 < m.mean() < 0.95
+    assert np.array_equal(t[m], recs["t"][m]) and np.array_equal(nrm[m], recs["normal"][m])
+    assert np.array_equal(mat[m], recs["material_id"][m].astype(np.uint32)) and np.array_equal(side[m], recs["side"][m])
