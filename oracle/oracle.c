@@ -271,7 +271,13 @@ void orc_to_gpu_camera(const OCamera* cam, uint32_t w, uint32_t h, OGPUCamera* o
 void orc_generate_ray(const OGPUCamera* camera, float x, float y, ORay* out)
 {
   const float aspect_ratio = (float)camera->width / (float)camera->height;
+#ifdef ORC_LIBM
+  /* "another libm": the tangent rounded from double precision (a correctly rounded tanf; glibc's differs from it by
+   * at most an ulp, CUDA's by a little more), see the ORC_LIBM note at random_in_unit_sphere */
+  const float viewport_height = 2.0f * (float)tan((double)(camera->vfov / 2));
+#else
   const float viewport_height = 2.0f * tanf(camera->vfov / 2);
+#endif
   const float viewport_width = aspect_ratio * viewport_height;
   const float focal_length = 1.0f;
 
@@ -816,7 +822,16 @@ static ovec3 random_in_unit_sphere(uint32_t* rng)
   const float cos_theta = 2.f * orc_rng_uniform(rng) - 1.f;
   const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
   float s, c;
+#ifdef ORC_LIBM
+  /* -DORC_LIBM (liboracle_libm.so, make -C oracle libm): the reference's own calls -- sinf / cosf here
+   * (distributions.cuh:13-17), pow(x, 5) in reflectance (path_tracer.cu:135), tan in generate_ray (ray_gen.cu:40) --
+   * through the platform's libm instead of the three fixed sequences both the oracle and the kernels use.  Only
+   * tests/test_oracle_libm.py loads this build: it measures what the substitutions change in the image. */
+  s = sinf(phi);
+  c = cosf(phi);
+#else
   orc_sincos(phi, &s, &c);
+#endif
   return v3(c * sin_theta, s * sin_theta, cos_theta);
 }
 
@@ -824,10 +839,14 @@ static float reflectance(float cosine, float ref_idx)
 {
   float r0 = (1 - ref_idx) / (1 + ref_idx);
   r0 = r0 * r0;
+#ifdef ORC_LIBM
+  return r0 + (1 - r0) * powf(1 - cosine, 5);
+#else
   const float x = 1 - cosine;
   const float x2 = x * x;
   const float x4 = x2 * x2;
   return r0 + (1 - r0) * (x4 * x);
+#endif
 }
 
 /* glm::sign */
