@@ -18,5 +18,6 @@ pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 cd $ROOT
 python3 tools/pmc_summary.py $OUT k_traverse4 > $OUT/summary.txt 2>&1
 python3 tools/pmc_json.py $OUT k_traverse4 $FPL >> $OUT/summary.txt 2>&1
+python3 tools/pmc_summary.py $OUT k_shade_fused > $OUT/summary_shade.txt 2>&1   # N1: what the material switch costs
 for d in fetch write rdreq sq1 sq2 tcc tcp; do rm -rf $OUT/$d/*/*.db; done
 cat $OUT/summary.txt
