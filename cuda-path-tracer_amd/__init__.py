@@ -4,7 +4,7 @@ The directory name contains a hyphen, so it is imported through ``__graft_entry_
 under the module name ``cuda_path_tracer_amd``.  All rendering happens in ``libptcore.so``
 (``csrc/``, C ABI in ``include/ptcore.h``); the Python files are the host-side mirror of the reference's
 ``PathTracer`` / ``SceneDescription`` interface used by the tests and by bench.py."""
-from . import _capi, bands, glmlite, json_parser, scenes
+from . import _capi, bands, camera_controller, glmlite, json_parser, scenes, viewer
 from ._capi import LIB_PATH, PtcError, lib
 from .path_tracer import DisplayBufferType, EdgeAvoidingATrousDenoiser, GPUMethod, PathTracer
 from .scene_description import (Camera, DielectricMaterial, DiffuseMateral, FlatScene, Mesh, MetalMaterial,

@@ -7,6 +7,9 @@
 // (DisplayBufferType of send_to_preview, path_tracer.cu:487-520: which buffer the PNG shows), --dump-raw FILE (the
 // accumulated float framebuffers as they are: "PTRF", width, height, 7 as uint32, then colour rgb, normal xyz and
 // depth planes as float32).  Without -o the reference opens its GLFW viewer; this build is headless and says so.
+// --replay SCRIPT.json: the viewer WITHOUT a window -- App::main_loop / run_cuda (interactive-app/app.cpp:141-170) driven by
+// a script of the events the reference takes from GLFW and ImGui (movement keys, right-drag, Space, the GUI's fields),
+// one PNG per displayed frame (see run_replay below).
 //
 // --gpus N: one PROCESS per GPU (forked before anything touches HIP), rank r on device r % device_count.  The frame's
 // rows are dealt to the ranks in blocks of 8 (ptc_set_interleave: sky rows are cheap, terrain rows expensive), the
@@ -23,10 +26,14 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <algorithm>
 #include <optional>
+#include <sstream>
 #include <string>
 #include <vector>
 
+#include "first_person_camera_controller.hpp"
+#include "json.hpp"
 #include "path_tracer.hpp"
 
 namespace fs = std::filesystem;
@@ -46,6 +53,8 @@ struct CliConfigurations {  // configurations.hpp:11-15
   std::optional<std::string> dump_scene;
   std::optional<std::string> dump_raw;
   DisplayBufferType display = DisplayBufferType::final;
+  std::optional<std::string> replay;
+  bool dry_run = false;
 };
 
 void usage()
@@ -62,7 +71,9 @@ void usage()
                "      --gpus N         split the frame's rows over N processes / GPUs (rank r on device r %% device count)\n"
                "      --dump-scene F   write the flattened scene to F and exit (no GPU needed)\n"
                "      --display D      buffer the image shows: final (default) | color | normal | depth\n"
-               "      --dump-raw F     also write the accumulated float buffers (colour, normal, depth) to F\n");
+               "      --dump-raw F     also write the accumulated float buffers (colour, normal, depth) to F\n"
+               "      --replay S.json  headless viewer: replay a script of viewer events, -o PREFIX -> PREFIX_0000.png ...\n"
+               "      --dry-run        with --replay: no GPU, no images; print the camera after every event\n");
 }
 
 CliConfigurations parse_cli_args(int argc, char** argv)
@@ -91,6 +102,8 @@ CliConfigurations parse_cli_args(int argc, char** argv)
     else if (a == "--gpus") c.gpus = std::stoi(need("gpus"));
     else if (a == "--dump-scene") c.dump_scene = need("dump-scene");
     else if (a == "--dump-raw") c.dump_raw = need("dump-raw");
+    else if (a == "--replay") c.replay = need("replay");
+    else if (a == "--dry-run") c.dry_run = true;
     else if (a == "--display") {
       const std::string d = need("display");
       if (d == "final") c.display = DisplayBufferType::final;
@@ -170,6 +183,139 @@ bool write_raw(const std::string& path, uint32_t width, uint32_t height, Fetch f
     out.write(reinterpret_cast<const char*>(plane.data()), (std::streamsize)(floats * sizeof(float)));
   }
   return (bool)out;
+}
+
+// ---- --replay: the interactive front-end without a window ---------------------------------------------------
+// What App does (interactive-app/app.cpp): own a PathTracer and a FirstPersonCameraController on the scene's camera
+// (:16-19), max_iterations = the scene's spp and buffers of the WINDOW's size, 800 x 800 (:36,127-131); then per loop
+// turn (:162-170) poll the events -- a movement key or a right-drag moves the camera and restarts the accumulation
+// (:64-67,108-113), Space restarts (:56), a resize reallocates (:45) -- run_cuda (:141-160: path_trace [+ denoise] +
+// synchronise, repeated for 16 ms, then send_to_preview of the chosen DisplayBufferType), and let the GUI edit
+// max_iterations, the method, the denoiser and the display (gui.cpp:84-108).  The script is those events:
+//   {"window": [w, h], "iterations_per_frame": 2, "events": [
+//      {"frames": 3},                      loop turns: run_cuda + one PNG each
+//      {"key": "W", "count": 5},           GLFW_REPEAT of W/A/S/D/R/F            {"mouse": [dx, dy]}   right-drag, pixels
+//      {"space": true}  {"resize": [w, h]}  {"denoise": true}  {"display": "normal"}  {"method": "megakernel"}
+//      {"max_iterations": 64}  {"filter_size": 10}  {"speed": 0.5}  {"position": [x, y, z]}  {"reset": true} ]}
+// A turn runs "iterations_per_frame" iterations (default 1) instead of as many as fit into 16 ms, so that a replay
+// gives the same frames every time; "budget_ms": 16 restores the reference's clock.
+int run_replay(const CliConfigurations& configs, SceneDescription& scene_desc)
+{
+  std::ifstream file(*configs.replay);
+  if (!file) throw std::runtime_error("Cannot open replay script " + *configs.replay);
+  std::stringstream text;
+  text << file.rdbuf();
+  const JsonPtr root = JsonReader(text.str()).parse();
+  UResolution resolution{800u, 800u};  // app.cpp:36
+  if (const Json* w = root->find("window")) resolution = {(unsigned)w->arr.at(0)->f(), (unsigned)w->arr.at(1)->f()};
+  const int per_frame = root->find("iterations_per_frame") ? (int)root->at("iterations_per_frame").f() : 1;
+  const double budget_ms = root->find("budget_ms") ? root->at("budget_ms").f() : 0.0;
+
+  Camera& camera = scene_desc.camera;
+  FirstPersonCameraController controller{camera};  // app.cpp:18 (reset(): the camera is re-expressed as yaw + pitch)
+  if (configs.dry_run) {  // the controller alone (no GPU): one line per event
+    std::printf("start: position %.9g %.9g %.9g yaw %.9g pitch %.9g rotation %.9g %.9g %.9g %.9g\n", camera.position[0], camera.position[1],
+                camera.position[2], controller.yaw(), controller.pitch(), camera.rotation_wxyz[0], camera.rotation_wxyz[1],
+                camera.rotation_wxyz[2], camera.rotation_wxyz[3]);
+    int restarts = 0;
+    for (const JsonPtr& ev : root->at("events").arr) {
+      bool moved = false;
+      if (const Json* j = ev->find("key")) {
+        const int count = ev->find("count") ? (int)ev->at("count").f() : 1;
+        for (int i = 0; i < count; ++i) moved = (!j->str.empty() && controller.on_key_press(j->str[0])) || moved;
+      } else if (const Json* j = ev->find("mouse")) {
+        const float rad = 0.01745329251994329576923690768489f;
+        moved = controller.on_mouse_move(rad * j->arr.at(0)->f(), rad * j->arr.at(1)->f());
+      } else if (const Json* j = ev->find("speed")) {
+        controller.speed = j->f();
+      } else if (const Json* j = ev->find("position")) {
+        controller.set_position(j->arr.at(0)->f(), j->arr.at(1)->f(), j->arr.at(2)->f());
+        controller.update_camera();
+        moved = true;
+      } else if (ev->find("reset")) {
+        controller.reset();
+        moved = true;
+      } else {
+        continue;
+      }
+      restarts += moved ? 1 : 0;
+      std::printf("event: position %.9g %.9g %.9g yaw %.9g pitch %.9g rotation %.9g %.9g %.9g %.9g restarts %d\n", camera.position[0],
+                  camera.position[1], camera.position[2], controller.yaw(), controller.pitch(), camera.rotation_wxyz[0],
+                  camera.rotation_wxyz[1], camera.rotation_wxyz[2], camera.rotation_wxyz[3], restarts);
+    }
+    return 0;
+  }
+  PathTracer path_tracer{configs.gpu};
+  path_tracer.max_bounces = configs.max_bounces;
+  path_tracer.max_iterations = scene_desc.spp;      // app.cpp:130
+  path_tracer.create_buffers(resolution, scene_desc);
+  bool enable_denoising = configs.denoise;
+  DisplayBufferType display = configs.display;
+  if (configs.megakernel) path_tracer.current_gpu_method = GPUMethod::megakernel;
+
+  int shown = 0;
+  std::vector<uchar4> buffer;
+  auto turn = [&]() {  // run_cuda, app.cpp:141-160
+    const auto start = std::chrono::steady_clock::now();
+    int done = 0;
+    do {
+      path_tracer.path_trace(camera, resolution);
+      if (enable_denoising) path_tracer.denoise(resolution);
+      path_tracer.synchronize();
+      ++done;
+    } while (budget_ms > 0.0 ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count() < budget_ms
+                             : done < per_frame);
+    buffer.resize((size_t)resolution.width * resolution.height);
+    path_tracer.send_to_preview(buffer.data(), resolution, display);
+    char name[32];
+    std::snprintf(name, sizeof name, "_%04d.png", shown++);
+    if (!write_png(*configs.output_filename + name, (int)resolution.width, (int)resolution.height, buffer.data()))
+      throw std::runtime_error("Failed to write " + *configs.output_filename + name);
+  };
+  for (const JsonPtr& ev : root->at("events").arr) {
+    if (const Json* j = ev->find("frames")) {
+      for (int i = 0, n = (int)j->f(); i < n; ++i) turn();
+    } else if (const Json* j = ev->find("key")) {
+      const int count = ev->find("count") ? (int)ev->at("count").f() : 1;
+      for (int i = 0; i < count; ++i)
+        if (!j->str.empty() && controller.on_key_press(j->str[0])) path_tracer.restart();  // app.cpp:64-67
+    } else if (const Json* j = ev->find("mouse")) {
+      const float rad = 0.01745329251994329576923690768489f;  // glm::radians, app.cpp:110-111
+      if (controller.on_mouse_move(rad * j->arr.at(0)->f(), rad * j->arr.at(1)->f())) path_tracer.restart();
+    } else if (ev->find("space")) {
+      path_tracer.restart();  // app.cpp:56
+    } else if (const Json* j = ev->find("resize")) {
+      resolution = {(unsigned)j->arr.at(0)->f(), (unsigned)j->arr.at(1)->f()};
+      path_tracer.resize_image(resolution);  // app.cpp:45
+    } else if (const Json* j = ev->find("denoise")) {
+      enable_denoising = j->b;
+    } else if (const Json* j = ev->find("display")) {
+      display = j->str == "color" ? DisplayBufferType::color : j->str == "normal" ? DisplayBufferType::normal
+                : j->str == "depth" ? DisplayBufferType::depth : DisplayBufferType::final;
+    } else if (const Json* j = ev->find("method")) {
+      path_tracer.current_gpu_method = j->str == "megakernel" ? GPUMethod::megakernel : GPUMethod::streaming;
+    } else if (const Json* j = ev->find("max_iterations")) {
+      path_tracer.max_iterations = std::max(1, (int)j->f());  // gui.cpp:103-104
+    } else if (const Json* j = ev->find("filter_size")) {
+      path_tracer.atrous_denoiser.filter_size = (int)j->f();
+    } else if (const Json* j = ev->find("speed")) {
+      controller.speed = j->f();
+    } else if (const Json* j = ev->find("position")) {  // the camera panel's "Translation" field, first_person_camera_controller.cpp:121-126
+      controller.set_position(j->arr.at(0)->f(), j->arr.at(1)->f(), j->arr.at(2)->f());
+      controller.update_camera();
+      path_tracer.restart();
+    } else if (ev->find("reset")) {
+      controller.reset();
+      path_tracer.restart();
+    } else {
+      throw std::runtime_error("replay: unknown event");
+    }
+  }
+  const ptc_stats st = path_tracer.stats();
+  std::printf("replayed %s: %d frames shown, %llu rays, camera at (%g, %g, %g) yaw %g pitch %g\n", configs.replay->c_str(), shown,
+              (unsigned long long)st.rays_total, camera.position[0], camera.position[1], camera.position[2], controller.yaw(),
+              controller.pitch());
+  return 0;
 }
 
 // ---- --gpus N -------------------------------------------------------------------------------------------------
@@ -366,11 +512,13 @@ try {
     out.write(reinterpret_cast<const char*>(tail), sizeof tail);
     return 0;
   }
+  if (configs.replay && configs.dry_run) return run_replay(configs, scene_desc);
   if (!configs.output_filename) {
-    std::fprintf(stderr, "hip_pt: this build is headless (no GLFW viewer); give -o <file.png>\n");
+    std::fprintf(stderr, "hip_pt: this build is headless (no GLFW viewer); give -o <file.png>, or --replay <script.json> -o <prefix>\n");
     return 1;
   }
 
+  if (configs.replay) return run_replay(configs, scene_desc);
   if (configs.gpus > 1) return run_ranks(configs, scene_desc);
 
   const UResolution resolution{(unsigned)scene_desc.resolution[0], (unsigned)scene_desc.resolution[1]};
