@@ -2,7 +2,9 @@
 // (/root/reference/src/interactive-app/first_person_camera_controller.{hpp,cpp}), restated without glm / GLFW / ImGui:
 // position + pitch + yaw, w/a/s/d/r/f move along the camera's axes, a right-drag turns it.  Keys are the characters
 // the reference binds ('W' forward ... GLFW_KEY_W == 'W').  Every function cites the lines it follows; float32 math in
-// glm's operation order (host side, not on the parity path).
+// glm's operation order (host side, not on the parity path).  Transcendentals are evaluated in double precision and
+// rounded to float -- the Python mirror (camera_controller.py) does the same through math.*, so the two front-ends hand
+// the render core the same camera bits and their replays show the same frames.
 #pragma once
 
 #include <cmath>
@@ -35,7 +37,7 @@ public:
   void set_yaw(float yaw) noexcept  // cpp:45-52: wrapped into [-pi, pi)
   {
     const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
-    yaw = std::fmod(yaw + pi, two_pi);
+    yaw = (float)std::fmod((double)(yaw + pi), (double)two_pi);
     if (yaw < 0.0f) yaw += two_pi;
     yaw_ = yaw - pi;
   }
@@ -48,11 +50,12 @@ public:
     // glm::pitch (gtc/quaternion.inl): atan(2 (y z + w x), w w - x x - y y + z z), 2 atan(x, w) when both vanish
     const float py = 2.0f * (y * z + w * x), px = w * w - x * x - y * y + z * z;
     const float eps = 1.1920929e-7f;
-    pitch_ = (std::fabs(px) <= eps && std::fabs(py) <= eps) ? 2.0f * std::atan2(x, w) : std::atan2(py, px);
+    pitch_ = (std::fabs(px) <= eps && std::fabs(py) <= eps) ? 2.0f * (float)std::atan2((double)x, (double)w)
+                                                             : (float)std::atan2((double)py, (double)px);
     // glm::yaw: asin(clamp(-2 (x z - w y), -1, 1))
     float sy = -2.0f * (x * z - w * y);
     sy = sy < -1.0f ? -1.0f : (sy > 1.0f ? 1.0f : sy);
-    yaw_ = std::asin(sy);
+    yaw_ = (float)std::asin((double)sy);
     speed = default_speed;
     update_camera();
   }
@@ -98,7 +101,8 @@ public:
   // glm::yawPitchRoll(yaw, pitch, 0) (gtx/euler_angles.inl), upper 3x3, column-major m[3 * col + row]
   static void yaw_pitch(float yaw, float pitch, float m[9])
   {
-    const float ch = std::cos(yaw), sh = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+    const float ch = (float)std::cos((double)yaw), sh = (float)std::sin((double)yaw);
+    const float cp = (float)std::cos((double)pitch), sp = (float)std::sin((double)pitch);
     m[0] = ch;       m[1] = 0.0f;  m[2] = -sh;
     m[3] = sh * sp;  m[4] = cp;    m[5] = ch * sp;
     m[6] = sh * cp;  m[7] = -sp;   m[8] = ch * cp;
@@ -113,7 +117,7 @@ public:
     if (fx > big) { big = fx; biggest = 1; }
     if (fy > big) { big = fy; biggest = 2; }
     if (fz > big) { big = fz; biggest = 3; }
-    const float val = std::sqrt(big + 1.0f) * 0.5f, mult = 0.25f / val;
+    const float val = (float)std::sqrt((double)(big + 1.0f)) * 0.5f, mult = 0.25f / val;
     switch (biggest) {
     case 0: wxyz[0] = val; wxyz[1] = (m12 - m21) * mult; wxyz[2] = (m20 - m02) * mult; wxyz[3] = (m01 - m10) * mult; break;
     case 1: wxyz[0] = (m12 - m21) * mult; wxyz[1] = val; wxyz[2] = (m01 + m10) * mult; wxyz[3] = (m20 + m02) * mult; break;

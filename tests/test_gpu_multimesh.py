@@ -340,6 +340,7 @@ def test_run_of_instances_against_the_oracle(pkg, orc):
             for k, v in params:
                 pt.set_param(k, v)
             pt.create_buffers((128, 96), flat)
+            pt.max_iterations = 3
             for _ in range(3):
                 pt.path_trace(cam)
             for k in ("color", "normal", "depth"):
