@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()
 out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/sim_case.bin"
-W, H = 480, 270
+full = len(sys.argv) > 2 and sys.argv[2] == "full"     # packet_sim.cpp: every primary ray of the 1920 x 1080 frame, no bounce rays
+W, H = (1920, 1080) if full else (480, 270)
 scene = pkg.scenes.heightfield_scene((W, H)); flat = scene.build_scene()
 flat.bvh, depth = pkg.bvh_from_mesh(list(scene.mesh_map_.values())[0])
 # mesh only: drop the spheres (objects[0] is the mesh with an identity transform)
@@ -33,7 +34,7 @@ rays[:, 0:3] = pos; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.finfo(n
 all_rays = [rays]
 rng = np.random.default_rng(1)
 cur = rays
-for bounce in range(3):
+for bounce in range(0 if full else 3):
     recs, hit = orc.intersect_rays(mesh_only, cur)
     m = hit.astype(bool)
     p = cur[m, 0:3] + cur[m, 4:7] * recs["t"][m][:, None]
