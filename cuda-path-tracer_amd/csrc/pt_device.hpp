@@ -31,7 +31,7 @@ static_assert(kLds4 >= 4 && kLds4 <= kStackDepth, "PT_T4_LDS out of range");
 
 // error bits in DeviceCounters::flags
 constexpr uint32_t kFlagStackOverflow = 1u;
-constexpr uint32_t kFlagDispatchOrder = 2u;  // k_shade_fused gave up waiting for a workgroup that was never dispatched
+constexpr uint32_t kFlagDispatchOrder = 2u;  // k_shade_fused gave up waiting for a predecessor tile (bounded look-back wait)
 
 // Same 160-byte layout as ptc_object / the reference's GPUObject (scene.hpp:16-22)
 struct DObject {
@@ -185,6 +185,7 @@ struct DeviceCounters {
   uint32_t flags;
   uint32_t slow_count;             // rays set aside for the exact redo by the running traversal launch
   uint32_t waves_done;             // wavefronts of the running traversal launch that have signed off
+  uint32_t shade_ticket;           // k_shade_fused: next tile of this frame to be taken (zero between launches)
   unsigned long long rays_total;
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only

@@ -915,6 +915,7 @@ struct BatchFeed {
 #define PT_FLAT_TRI 1
 #endif
 
+
 // End of a persistent traversal launch, run by its LAST wavefront (after the exact redo): the bookkeeping of the next
 // launch on this stream starts from zero -- the redo list, the sign-off counter and the fetch cursors of this launch's
 // set for every frame of the batch (plain stores: the next launch starts after this one has completed).
@@ -1700,15 +1701,15 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 //     its paths survive -- so the tile's survivor count is published after ONE round trip to memory;
 //   * the stable offset of the tile = survivors of all tiles before it, found by decoupled look-back over the tile
 //     descriptors (aggregate / inclusive prefix, Merrill & Garland): a wavefront reads up to 64 predecessors at once;
-//   * tile = blockIdx / frames (blocks are numbered frame-fastest).  A workgroup that waits for a predecessor's descriptor
-//     relies on that predecessor having been dispatched: workgroups of a grid are handed out in ascending order (each
-//     XCD takes its share in order; the slots a later workgroup could block are never the ones an earlier one of the
-//     same XCD is waiting for, and the other stream's persistent traversal wavefronts leave on their own).  HIP does
-//     not promise that order, so the wait is BOUNDED: a workgroup that has waited about a second sets
-//     kFlagDispatchOrder and gives up -- ptc_get_stats then reports an error instead of an image (never seen in any
-//     run; "fused_shade" 0 selects the three-kernel path, which has no wait between workgroups).  Taking the tiles by
-//     ticket instead (one atomic per workgroup, the textbook way) was measured: the atomic's round trip sits in front
-//     of every workgroup's first load and cost 3 % of the whole frame (profiles/r03_fused_shade_ab.txt);
+//   * tiles are taken in TICKET order (one agent-scope atomic per workgroup on the frame's counter line; blocks are
+//     numbered frame-fastest, so neighbouring workgroups of a batch take their tickets on different lines), not in
+//     blockIdx order: whoever waits for a tile's descriptor waits for a workgroup that is RUNNING (it has its ticket),
+//     whatever else holds the chip's wavefront slots.  Block order is 1-3 % faster (the ticket's round trip sits in
+//     front of a workgroup's first load) and is NOT safe: with several streams' kernels on the chip, workgroups of
+//     one kernel fill an XCD spinning for a predecessor that waits for a slot on an XCD filled by another kernel's
+//     spinners -- seen once in 67 GPU tests x several runs (ten one-frame launches on ten streams), caught by the
+//     bounded wait below.  The wait stays bounded all the same: a workgroup that has waited about a second sets
+//     kFlagDispatchOrder and ptc_get_stats reports an error instead of an image;
 //   * descriptors carry the launch's epoch, so nothing has to be cleared between launches.
 // Same arithmetic and same slot order as the three kernels it replaces: images are bit-identical (tests).
 #ifndef PT_FUSE_K
@@ -1762,12 +1763,12 @@ __device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc
 }
 
 template <bool kSpheres, bool kFirst>
-__global__ __launch_bounds__(256) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
                                                      int staged, int bounce, int last_bounce, const uint32_t* slot_base,
                                                      unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb,
                                                      DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi)
 {
-  __shared__ uint32_t s_excl;
+  __shared__ uint32_t s_excl, s_tile;
   __shared__ uint32_t s_cnt[kFuseK * 4];
   const uint32_t frame = blockIdx.x % bi.count;  // frame-fastest: neighbouring blocks take their tickets on different lines
   const uint32_t iteration = bi.iteration[frame];
@@ -1790,12 +1791,19 @@ __global__ __launch_bounds__(256) void k_shade_fused(DScene sc, uint32_t obj_beg
   counters += frame;
   const uint32_t n = counters->live[bounce];
   const uint32_t tiles = (n + kFuseTile - 1u) / kFuseTile;
-  const uint32_t tile = blockIdx.x / bi.count;
+  const uint32_t wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0u) {
+    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every workgroup of the frame has its ticket once the last one is out: the next launch starts from zero
+    if (t + 1u == gridDim.x / bi.count) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
   if (tile >= tiles) {
     if (tiles == 0u && tile == 0u && threadIdx.x == 0u) counters->live[bounce + 1] = 0u;  // nothing alive: nothing follows
     return;
   }
-  const uint32_t wave = threadIdx.x >> 6;
 
   // ---- phase 1: rays and hits of the tile; the closest hit is final after the trailing sphere run ----
   float4 o4[kFuseK], d4[kFuseK], tp[kFuseK], nm[kFuseK];

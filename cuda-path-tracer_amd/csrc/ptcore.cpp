@@ -1803,8 +1803,8 @@ int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
   out->stack_capacity = kStackDepth;
   if (flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow during rendering");
   if (flags & kFlagDispatchOrder)
-    return fail(ctx, PTC_ERR_HIP, "k_shade_fused waited for a workgroup that was never dispatched (workgroups out of order): "
-                                  "the image is invalid; set the parameter \"fused_shade\" to 0 on this system");
+    return fail(ctx, PTC_ERR_HIP, "k_shade_fused gave up waiting for a predecessor tile's survivor count: the image is invalid "
+                                  "(set the parameter \"fused_shade\" to 0 to use the three-kernel path)");
   return PTC_OK;
 }
 
