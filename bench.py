@@ -93,6 +93,9 @@ def parse():
                          "library's inter-process gather (ptc_band_* / ptc_gather_frame, what hip_pt --gpus N uses)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and talk over gloo (to rehearse the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--share-of", type=int, default=0, metavar="N",
+                    help="diagnostic, one process: trace only rank 0's rows of an N-way split with the schedule an N-GPU run "
+                         "would pick (how long does ONE rank of --gpus N take?  no gather, not a whole-job number)")
     ap.add_argument("--no-events", action="store_true", help="do not time the trace kernel with HIP events (diagnostic)")
     ap.add_argument("--cpu-sample", type=str, default="", help="resolution of the CPU-oracle sample frames (default: the full frame)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="iterations the CPU oracle renders (cpu_baseline sample and parity frame): "
@@ -203,7 +206,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     bare = copy.copy(flat)
     bare.bvh = None   # the tracer gets the scene as the reference's front end hands it over: the library builds BVH and layouts (on the GPU)
     startup = {}
-    rank_rows = pkg.bands.interleaved_rows(H, world, BLOCK_ROWS)
+    split = args.share_of if (args.share_of > 1 and world == 1) else world   # ranks the frame's rows are dealt to
+    rank_rows = pkg.bands.interleaved_rows(H, split, BLOCK_ROWS)
 
     # Schedule: `batch` consecutive frames share every launch (the latency tail of a bounce -- a few long rays --
     # and the drain of the persistent wavefronts are paid once per batch) and `streams` batches are in flight so
@@ -211,13 +215,18 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     # value; a timed region shorter than one round of full batches (the driver's --steps 20) is split evenly over
     # the streams instead, and the tuned schedule is reported beside it (steady_state).  Results do not depend on
     # any of it (tests/test_gpu_schedules.py).
-    streams = args.streams or (2 if world <= 2 else 4)
+    streams = args.streams or (2 if split <= 2 else 4)
     if args.batch_frames:
         batch = args.batch_frames
     elif args.steps >= streams * 32:
         batch = 32
-    elif args.steps <= 32:
+    elif args.steps <= 32 and split < 4:
         batch, streams = args.steps, 1      # one launch sequence carries them all (measured: 1 x 20 beats 2 x 10 and 4 x 5)
+    elif args.steps <= 32:
+        # a rank of four or eight: its launches are small enough to be bound by the tail of their longest rays, and two
+        # half-size sequences overlap those tails (measured with --share-of: 1/8 of the frame 0.159 vs 0.169 ms per step,
+        # 1/4 0.257 vs 0.281; 4 x 5 loses again)
+        batch, streams = -(-args.steps // 2), 2
     else:
         batch = max(1, min(32, -(-args.steps // streams)))
 
@@ -227,7 +236,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.set_param("batch_frames", batch_frames)
         # persistent traversal wavefronts per launch: what is resident at 5 per SIMD on one GPU; half of that for
         # the smaller launches of a rank among 4 or 8
-        pt.set_param("traverse_waves", args.traverse_waves or (5120 if world <= 2 else 2560))
+        pt.set_param("traverse_waves", args.traverse_waves or (5120 if split <= 2 else 2560))
         pt.set_param("ray_sort", args.ray_sort)
         if args.trace_variant >= 0:
             pt.set_trace_variant(args.trace_variant)
@@ -237,8 +246,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.create_buffers((W, H), bare)
         startup.update(pt.upload_times())
         pt.set_stream(torch.cuda.current_stream().cuda_stream)
-        if world > 1:
-            pt.set_interleave(rank, world, BLOCK_ROWS)
+        if split > 1:
+            pt.set_interleave(rank, split, BLOCK_ROWS)
             # every rank numbers its compacted paths from 0 (no collective while tracing): an offset keeps the
             # ranks' random streams apart (the material RNG is keyed on the slot index, path_tracer.cu:300)
             pt.set_param("slot_offset", rank * W * H)
@@ -392,7 +401,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     timed_frames = None
     cw, ch = (int(v) for v in args.cpu_sample.split("x")) if args.cpu_sample else (W, H)
     cpu_frames = max(1, min(args.cpu_frames, args.steps))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and (cw, ch) == (W, H):
+    if rank == 0 and split == 1 and not args.no_cpu_baseline and (cw, ch) == (W, H):
         pt.restart()
         r0 = pt.stats()["rays_total"]
         for _ in range(cpu_frames):
@@ -402,21 +411,21 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         timed_frames["rays"] = st["rays_total"] - r0
         timed_frames["last_live"] = st["last_live"]
     # (the counter records under profiles/ were taken on the default workload with the default kernel)
-    pmc_scene = args.grid == "1001x501" and (W, H, MB) == (1920, 1080, 8) and args.trace_variant in (-1, 3) and world == 1
+    pmc_scene = args.grid == "1001x501" and (W, H, MB) == (1920, 1080, 8) and args.trace_variant in (-1, 3) and split == 1
     roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=pmc_scene,
-                              pixels=W * H // world, frames=args.steps)
+                              pixels=W * H // split, frames=args.steps)
     slow_rays = sum(prof["slow_rays"])
 
     # the tuned schedule on the same workload (only when the timed region above was too short to show it)
     steady = None
     if not args.no_extras and (batch != 32 or args.steps < 256):
-        tuned_streams = args.streams or (2 if world <= 2 else 4)   # (not the single stream of a short timed region)
+        tuned_streams = args.streams or (2 if split <= 2 else 4)   # (not the single stream of a short timed region)
         if batch != 32 or streams != tuned_streams:
             pt.close()
             pt = make_tracer(32, tuned_streams)
         s_el, s_rays, s_prof, s_first = timed(pt, 256, 64)
         s_counted = count_tests(pt, s_first, 4)
-        s_roof = trace_roofline(s_prof, s_counted, list(s_prof["paths"]), MB, s_el, 32, pmc_scene=pmc_scene, pixels=W * H // world, frames=256)
+        s_roof = trace_roofline(s_prof, s_counted, list(s_prof["paths"]), MB, s_el, 32, pmc_scene=pmc_scene, pixels=W * H // split, frames=256)
         steady = {"value": round(s_rays / s_el / 1e6, 3), "unit": "Mrays/s", "steps": 256, "warmup": 64, "frames_per_launch": 32,
                   "frames_in_flight": tuned_streams * 32, "ms_per_step": round(s_el / 256 * 1e3, 4),
                   "roofline_frac": s_roof["frac"], "roofline_achieved": s_roof["achieved"],
@@ -427,7 +436,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
 
     # single-frame latency: strictly serial frames, and the viewer pattern (app.cpp:141-170 presents every frame)
     latency = None
-    if not args.no_extras and world == 1:
+    if not args.no_extras and split == 1:
         latency = {}
         rgba = torch.empty((H, W), dtype=torch.int32, device="cuda")
         for key, fif, every in (("serial_frame_ms", 1, False), ("present_every_frame_ms", 4, True)):
@@ -453,7 +462,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             lp.close()
 
     cpu_baseline = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and split == 1 and not args.no_cpu_baseline:
         orc = graft.load_oracle()
         sh = orc.SceneHandle(flat)
         cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
@@ -502,7 +511,9 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                                      f"{batch} frames; the tuned 32-frame schedule is reported under steady_state"),
                    "rays_per_step": round(rays / args.steps),
                    "live_per_bounce_last_frame_rank0": last_live, "exact_redo_rays": slow_rays,
-                   "partition": "full frame" if world == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {world} ranks; "
+                   "diagnostic": (f"--share-of {split}: ONE rank's rows of a {split}-way split traced on one GPU (no gather); value is that "
+                                  "rank's own rate, not a job's") if split != world else None,
+                   "partition": "full frame" if split == 1 else f"rows in blocks of {BLOCK_ROWS} dealt round-robin over {split} ranks; "
                                 f"present-time gather: {args.gather}",
                    "startup": {"scene_upload_ms": startup, "note": "ptc_upload_scene of the scene without BVH: reference BVH (bit-identical "
                                "to the host builder's) and traversal layouts built on the GPU", "host_bvh_builder_s": round(bvh_build_s, 3)}},
