@@ -659,7 +659,8 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
   generate_ray(cam, fx, fy, o, d);
   stnt(&paths.o4[s], make_float4(o.x, o.y, o.z, __uint_as_float(pixel)));
   stnt(&paths.d4[s], make_float4(d.x, d.y, d.z, 0.0f));
-  stnt(&paths.t4[s], make_float4(1.0f, 1.0f, 1.0f, 0.0f));
+  // (the throughput of a primary ray is (1, 1, 1), ray_gen.cu:25: the shade kernels know that at bounce 0 and neither
+  // is it written here nor read there -- 32 bytes per pixel and frame less)
 }
 
 __device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
@@ -1643,7 +1644,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   if (active) {
     const float4 o4 = ldnt(&in.o4[s]);
     const float4 d4 = ldnt(&in.d4[s]);
-    const float4 t4 = ldnt(&in.t4[s]);
+    const float4 t4 = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ldnt(&in.t4[s]);  // (k_raygen does not write it)
     const float4 tp = ldnt(&hits.tp[s]);
     ro = xyz(o4);
     rd = xyz(d4);
@@ -1848,7 +1849,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   for (int j = 0; j < kFuseK; ++j) {
     const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
     t4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < n) t4[j] = ldnt(&in.t4[s]);
+    if (s < n) t4[j] = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ldnt(&in.t4[s]);  // (k_raygen does not write it)
     if (!kFirst && (hit_mask >> j & 1u) && !(have_nm >> j & 1u)) nm[j] = ldnt(&hits.nm[s]);
   }
   __syncthreads();
