@@ -258,11 +258,15 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     # gather needs equal sizes on every rank: pad each rank's rows to the largest share
     max_rows = max(len(rr) for rr in rank_rows)
     band_color = torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda")
-    gathered = frame = row_index = None
+    gathered = frame = row_index = gathered_all = frame_pad = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty((max_rows, W, 3), dtype=torch.float32, device="cuda") for r in range(world)]
-        frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-        row_index = [torch.tensor(rank_rows[r], dtype=torch.long, device="cuda") for r in range(world)]
+        # the ranks' (padded) bands land in ONE tensor and go into row order with ONE index_copy: row H of frame_pad takes
+        # the padding rows of the ranks that own fewer rows than the largest share
+        gathered_all = torch.empty((world, max_rows, W, 3), dtype=torch.float32, device="cuda")
+        gathered = [gathered_all[r] for r in range(world)]
+        frame_pad = torch.empty((H + 1, W, 3), dtype=torch.float32, device="cuda")
+        frame = frame_pad[:H]
+        row_index = torch.tensor([rr[k] if k < len(rr) else H for rr in rank_rows for k in range(max_rows)], dtype=torch.long, device="cuda")
 
     ipc_gathers = {}
 
@@ -284,8 +288,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             else:
                 dist.gather(band_color, gathered if rank == 0 else None, dst=0)
             if rank == 0:
-                for r in range(world):
-                    frame.index_copy_(0, row_index[r], gathered[r][: len(rank_rows[r])])
+                frame_pad.index_copy_(0, row_index, gathered_all.view(world * max_rows, W, 3))
 
     def fence():
         if world > 1:
@@ -360,6 +363,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             e1.record()
             torch.cuda.synchronize()
             us.append(e0.elapsed_time(e1) * 1e3)
+        rccl_frame = frame.clone() if rank == 0 else None
         gather["rccl_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
         gather["rccl_note"] = "pack + dist.gather + index_copy into row order, rank 0's stream, median of 5"
         # the library's gather: handles once, then publish / barrier / pull
@@ -390,6 +394,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                     us.append(pt.gather_last_us())
                 dist.barrier()
             gather["ipc_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
+            gather["transports_agree"] = bool(torch.equal(rccl_frame, frame)) if rank == 0 else None   # the same assembled frame, bit for bit
             gather["ipc_note"] = ("ptc_gather_frame: one kernel on the root reads every rank's band where it lies (HIP IPC "
                                   "mapping; xGMI between GPUs) and writes row order; device time, median of 5")
         else:

@@ -100,6 +100,7 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0
     assert d["rccl_ranks"] == 0 and "gloo" in d["gather"]["backend"]          # a rehearsal says so
     assert d["gather"]["rccl_us"] > 0 and d["gather"]["ipc_us"] > 0, d["gather"]
+    assert d["gather"]["transports_agree"] is True      # the RCCL-path frame and the library's gathered frame are the same bits
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["rays"] > 0 for r in d["ranks"])
     assert abs(sum(r["rays"] for r in d["ranks"]) - d["config"]["rays_per_step"] * 20) <= 20
     import torch
