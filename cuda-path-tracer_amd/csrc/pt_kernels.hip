@@ -739,7 +739,18 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 // Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test, path_tracer.cu:78-100)
 // for one ray whose closest hit so far is ray.tmax (FLT_MAX: none).  A sphere that is hit replaces `rec`, shrinks
 // ray.tmax and sets `changed`.  Used by k_spheres (a run in front of a mesh, a scene without a mesh) and by
-// k_count_scan (the run behind the last mesh).
+// the kernel that ends the bounce (k_shade_fused / k_tail_count: the run behind the last mesh).
+// transform_point (transform.hpp:37-42) divides by w.  For an affine matrix w is exactly 1 whatever the (finite) point --
+// (0 x + 0 y) + (0 z + 1) -- and x / 1 is x: when every lane of the wavefront has w == 1 the three IEEE divisions (ten
+// instructions each) are skipped; the result has the same bits.  Any lane with another w (a projective matrix, a
+// non-finite coordinate) sends the wavefront through the divisions.
+__device__ __forceinline__ f3 xform_point_w1(const m4& m, f3 p)
+{
+  const f4 v = mul(m, p.x, p.y, p.z, 1.0f);
+  if (__builtin_expect(__ballot(v.w != 1.0f) == 0ull, 1)) return mk3(v.x, v.y, v.z);
+  return mk3(v.x, v.y, v.z) / v.w;
+}
+
 __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_begin, uint32_t obj_end, Ray& ray, Hit& rec,
                                                bool& changed)
 {
@@ -767,12 +778,13 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
       if (!pass) continue;
     }
     Ray tr;
-    inverse_transform_ray(obj->inv_m, ray, tr.o, tr.d);
+    tr.o = xform_point_w1(obj->inv_m, ray.o);  // inverse_transform_ray, transform.hpp:51-58
+    tr.d = normalize(xform_vector(obj->inv_m, ray.d));
     tr.tmin = ray.tmin;
     tr.tmax = ray.tmax;
     const float4 sp = sc.spheres[obj->index];
     if (ray_sphere(tr, xyz(sp), sp.w, rec)) {
-      rec.p = xform_point(obj->m, rec.p);
+      rec.p = xform_point_w1(obj->m, rec.p);
       rec.t = length(rec.p - ray.o);
       rec.n = xform_normal(obj->inv_m, rec.n);
       rec.mat = sc.object_material[i];
@@ -1044,7 +1056,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           const f3 oo = xform_point(obj->inv_m, ro);
           float en, ef;
           if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u) {
-            // a ray grazing the parent's box within rounding: redone in the reference's order by k_slow_rays
+            // a ray grazing the parent's box within rounding: redone with exact box decisions by the launch's epilogue (redo_slow_rays)
             set_aside(counters, slow_list, slot);
             best_k = -2;
           }
@@ -1211,7 +1223,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z) && finite_f(tol.x + tol.y + tol.z)) ||
                                sc.force_slow == 1u, 0)) {
             // degenerate direction (0/0 or overflow in the slab terms voids the error bound): set aside for
-            // k_slow_rays, which walks the tree in the reference's own order
+            // the launch's epilogue (redo_slow_rays), which takes every box decision with the reference's own test
             set_aside(counters, slow_list, slot);
             wrote = true;
             go = false;
@@ -1492,7 +1504,7 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 
 // A run of sphere objects that does not end the object list (the spheres in front of a mesh), continuing from /
 // handing on the closest hit in the hit record.  (The run that ENDS the list -- or is the whole list -- is part of
-// k_count_scan.)  (Taking the sphere runs into the traversal kernel instead was tried in round 2: inlined or as a
+// the kernel that ends the bounce.)  (Taking the sphere runs into the traversal kernel instead was tried in round 2: inlined or as a
 // call, their temporaries pushed loop-carried state of the walk into scratch, with reloads inside its hot loop.)
 template <bool kFirst>
 __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,

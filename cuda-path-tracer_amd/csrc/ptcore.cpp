@@ -160,7 +160,7 @@ struct ptc_ctx {
   int trace_variant = 3;  // 3: persistent lanes over the four-wide collapse, conservative FMA slabs, exact check of the winner (default); 0: reference-order traversal; 1: culled near-first traversal with exact box decisions
   // The closest-hit stage of the default variant, in object order: per mesh object a k_spheres launch for the run of
   // spheres in front of it ([pre_begin, pre_end), if it holds any) and a persistent traversal launch; the run that
-  // ends the object list ([tail_begin, tail_end): everything, in a scene without a mesh) is part of k_count_scan.
+  // ends the object list ([tail_begin, tail_end): everything, in a scene without a mesh) is tested by the kernel that ends the bounce (k_shade_fused; k_tail_count in the three-kernel form).
   struct TraceLaunch {
     uint32_t mesh, pre_begin, pre_end;
   };

@@ -1,5 +1,6 @@
 """N streaming frames of a named scene (workload for rocprofv3 runs); prints one JSON line with the ray count.
-usage: run_frames.py <heightfield|bunny|spheres> <frames> [batch_frames] [streams] [trace_variant]"""
+usage: run_frames.py <heightfield|bunny|spheres> <frames> [batch_frames] [streams] [trace_variant] [name=value ...]
+(name=value: ptc_set_param before the scene upload, e.g. fused_shade=0)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
@@ -7,7 +8,8 @@ pkg = g.load_package()
 which = sys.argv[1]; n = int(sys.argv[2])
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 streams = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-variant = int(sys.argv[5]) if len(sys.argv) > 5 else -1
+variant = int(sys.argv[5]) if len(sys.argv) > 5 and "=" not in sys.argv[5] else -1
+params = [a.split("=") for a in sys.argv[3:] if "=" in a]
 if which == 'heightfield':
     W, H = 1920, 1080; sc = pkg.scenes.heightfield_scene((W, H))
 elif which == 'bunny':
@@ -22,6 +24,8 @@ with pkg.PathTracer(max_bounces=8) as pt:
     pt.set_param("batch_frames", batch)
     if variant >= 0:
         pt.set_trace_variant(variant)
+    for name, value in params:
+        pt.set_param(name, int(value))
     pt.create_buffers((W, H), flat); pt.max_iterations = 1 << 30
     for _ in range(n):
         pt.path_trace(sc.camera)
