@@ -123,10 +123,15 @@ __device__ __forceinline__ bool ray_aabb(const f3 o, const f3 d, const f3 bmin, 
 }
 
 // ray_sphere_intersection_test, intersections.cuh:7-41
+// (a = dot(d, d) comes from the caller: sphere_segment can test many spheres with the same transformed direction)
+__device__ __forceinline__ bool ray_sphere_a(const Ray& ray, const float a, const f3 center, const float radius, Hit& rec);
 __device__ __forceinline__ bool ray_sphere(const Ray& ray, const f3 center, const float radius, Hit& rec)
 {
+  return ray_sphere_a(ray, dot(ray.d, ray.d), center, radius, rec);
+}
+__device__ __forceinline__ bool ray_sphere_a(const Ray& ray, const float a, const f3 center, const float radius, Hit& rec)
+{
   const f3 oc = ray.o - center;
-  const float a = dot(ray.d, ray.d);
   const float b = 2.0f * dot(ray.d, oc);
   const float c = dot(oc, oc) - radius * radius;
   const float disc = b * b - 4.0f * a * c;
@@ -751,6 +756,12 @@ __device__ __forceinline__ f3 xform_point_w1(const m4& m, f3 p)
   return mk3(v.x, v.y, v.z) / v.w;
 }
 
+// kShareDir (k_spheres only: it has the registers to spare; in k_shade_fused the three extra live values cost more than
+// they save, profiles/r03_sphere_math.txt): inverse_transform_ray's direction, normalize(M^-1 (d, 0)), is the same for
+// every object whose M^-1 has the identity as its upper 3 x 3 (a translated sphere: every sphere of the Cornell box) --
+// (1 dx + 0 dy) + (0 dz + t 0) is dx exactly when the components of d are finite and none is a zero (whose sign the sum
+// could change) -- so such a wavefront normalises its direction once for all of them.
+template <bool kShareDir = false>
 __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_begin, uint32_t obj_end, Ray& ray, Hit& rec,
                                                bool& changed)
 {
@@ -758,6 +769,10 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
   // divisions per object (below)
   const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
   const bool winv_ok = finite_f(winv.x + winv.y + winv.z);
+  const bool d_plain = kShareDir && finite_f(ray.d.x + ray.d.y + ray.d.z) && ray.d.x != 0.0f && ray.d.y != 0.0f && ray.d.z != 0.0f;
+  bool have_nd = false;
+  f3 nd = mk3(0.f, 0.f, 0.f);
+  float nd_a = 0.0f;
   for (uint32_t i = obj_begin; i < obj_end; ++i) {
     const DObject* obj = sc.objects + i;
     if (obj->type != 0u) continue;
@@ -779,11 +794,27 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
     }
     Ray tr;
     tr.o = xform_point_w1(obj->inv_m, ray.o);  // inverse_transform_ray, transform.hpp:51-58
-    tr.d = normalize(xform_vector(obj->inv_m, ray.d));
+    const m4& im = obj->inv_m;
+    const bool identity3 = kShareDir && im.c[0][0] == 1.0f && im.c[1][1] == 1.0f && im.c[2][2] == 1.0f && im.c[0][1] == 0.0f &&
+                           im.c[0][2] == 0.0f && im.c[1][0] == 0.0f && im.c[1][2] == 0.0f && im.c[2][0] == 0.0f &&
+                           im.c[2][1] == 0.0f;  // (wave-uniform: scalar loads and compares)
+    float a;
+    if (kShareDir && identity3 && __ballot(!d_plain) == 0ull) {
+      if (!have_nd) {
+        nd = normalize(ray.d);
+        nd_a = dot(nd, nd);
+        have_nd = true;
+      }
+      tr.d = nd;
+      a = nd_a;
+    } else {
+      tr.d = normalize(xform_vector(obj->inv_m, ray.d));
+      a = dot(tr.d, tr.d);
+    }
     tr.tmin = ray.tmin;
     tr.tmax = ray.tmax;
     const float4 sp = sc.spheres[obj->index];
-    if (ray_sphere(tr, xyz(sp), sp.w, rec)) {
+    if (ray_sphere_a(tr, a, xyz(sp), sp.w, rec)) {
       rec.p = xform_point_w1(obj->m, rec.p);
       rec.t = length(rec.p - ray.o);
       rec.n = xform_normal(obj->inv_m, rec.n);
@@ -1526,7 +1557,7 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   }
   Hit rec;
   bool changed = false;
-  sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
+  sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
   if (changed) store_hit(hits, s, rec);
   else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
 }
