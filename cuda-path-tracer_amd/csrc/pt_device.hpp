@@ -186,6 +186,7 @@ struct DeviceCounters {
   uint32_t slow_count;             // rays set aside for the exact redo by the running traversal launch
   uint32_t waves_done;             // wavefronts of the running traversal launch that have signed off
   uint32_t shade_ticket;           // k_shade_fused: next tile of this frame to be taken (zero between launches)
+  uint32_t list_count;             // rays k_spheres<.., kFilter> has put on the next traversal launch's work list (that launch zeroes it)
   unsigned long long rays_total;
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
@@ -261,15 +262,19 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
 //                     whole list) and the live count of every 64-slot chunk from the hit records; also after launch_trace
 //   launch_scan       exclusive scan of those counts (compaction offsets, live[bounce + 1])
 // first: nothing has written the hit records in this bounce yet
+// filt_begin < filt_end and worklist != null: also builds the work list of the traversal launch that follows over the mesh
+// objects [filt_begin, filt_end) (rays that surely miss all their world boxes are left out); that launch then gets
+// order = worklist, listed = true
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
-                    uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi);
+                    uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi, uint32_t filt_begin = 0u,
+                    uint32_t filt_end = 0u, uint32_t* worklist = nullptr);
 // a run [obj_begin, obj_end) of mesh objects of the SAME mesh in one launch (k_traverse4m): variant 3 only
 void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                          DHits hits, int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                         uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi);
+                         uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi, bool listed = false);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                     uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi);
+                     uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi, bool listed = false);
 // coherence sort of the pick-up order (never of the slots): octs = direction octant per slot (written by launch_shade
 // when given), order = per block of 4096 slots the slots grouped by octant; launch_traverse reads its rays through it
 void launch_sort_octant(hipStream_t s, const uint8_t* octs, uint32_t* order, uint32_t max_paths, int bounce,

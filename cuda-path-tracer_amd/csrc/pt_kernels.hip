@@ -650,6 +650,7 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   if (s == 0u) {
     counters->live[0] = pix_count;
+    counters->list_count = 0u;
   }
   if (blockIdx.x == 0u)  // fetch cursors of this frame's persistent traversal launches
     for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0][0])[i * 32u] = 0u;
@@ -851,6 +852,8 @@ __device__ __forceinline__ void store_hit(const DHits& hits, uint32_t slot, cons
 struct BatchFeed {
   DeviceCounters* ctr;
   uint32_t stride, count, bounce, work_slot, static_eighths, dyn_batch;
+  bool listed;  // the launch walks a work list (DeviceCounters::list_count entries per frame, read through `order`), not all live rays
+  __device__ __forceinline__ uint32_t rays_of(uint32_t f) const { return listed ? ctr[f].list_count : ctr[f].live[bounce]; }
   uint32_t home_f, home_r, home_base, stat_next, stat_step, stat_count;
   bool in_static, done;
 
@@ -865,9 +868,10 @@ struct BatchFeed {
     return ((len + kWave - 1u) / kWave) * static_eighths / 8u;
   }
   __device__ __forceinline__ void init(DeviceCounters* ctr_, const DBatchInfo& bi, int bounce_, int work_slot_,
-                                       uint32_t static_eighths_)
+                                       uint32_t static_eighths_, bool listed_ = false)
   {
     ctr = ctr_;
+    listed = listed_;
     stride = bi.stride;
     count = bi.count;
     bounce = (uint32_t)bounce_;
@@ -880,7 +884,7 @@ struct BatchFeed {
     const uint32_t with_r = (gridDim.x - home_r + 7u) / 8u;  // wavefronts of this r
     stat_step = (with_r - home_f + count - 1u) / count;      // ... of which this many share the home
     stat_next = j / count;
-    const uint32_t n = ctr[home_f].live[bounce];
+    const uint32_t n = rays_of(home_f);
     const uint32_t rs = region_size_of(n);
     stat_count = static_batches_of(region_len_of(n, rs, home_r));
     home_base = home_f * stride + home_r * rs;
@@ -914,7 +918,7 @@ struct BatchFeed {
           uint32_t f = home_f + df;
           if (f >= count) f -= count;
           const uint32_t r = (home_r + dr) & 7u;
-          const uint32_t n = ctr[f].live[bounce];
+          const uint32_t n = rays_of(f);
           const uint32_t rs = region_size_of(n);
           len = region_len_of(n, rs, r);
           first = static_batches_of(len) * kWave;
@@ -967,6 +971,7 @@ __device__ __forceinline__ void launch_epilogue(DeviceCounters* counters, int bo
                                                 const DBatchInfo& bi)
 {
   for (uint32_t i = threadIdx.x; i < bi.count * 8u; i += (uint32_t)kWave) counters[i >> 3].work[work_slot][i & 7u][0] = 0u;
+  for (uint32_t f = threadIdx.x; f < bi.count; f += (uint32_t)kWave) counters[f].list_count = 0u;  // (a work list is used once)
   if (threadIdx.x == 0u) {
     counters->slow_rays[bounce] += redone;
     counters->slow_count = 0u;
@@ -985,7 +990,7 @@ __device__ __forceinline__ void set_aside(DeviceCounters* counters, uint32_t* sl
 template <bool kCount, bool kFirst>
 __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
                                                int bounce, int work_slot, DeviceCounters* counters, uint32_t* slow_list,
-                                               const uint32_t* order, const DBatchInfo& bi)
+                                               const uint32_t* order, const DBatchInfo& bi, const bool listed)
 {
   __shared__ uint32_t s_stack[kLds4 * kWave];
   // work splitting at the end of a launch (see `split` below): per lane = per ray group led by that lane
@@ -1000,7 +1005,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   // `slot` below is batch-global (frame * bi.stride + slot in the frame); flags, the slow-ray list and the
   // test tallies of the whole batch go to frame 0's counters
   uint32_t n_max = 0u;
-  for (uint32_t f = 0; f < bi.count; ++f) n_max = max(n_max, counters[f].live[bounce]);
+  for (uint32_t f = 0; f < bi.count; ++f) n_max = max(n_max, listed ? counters[f].list_count : counters[f].live[bounce]);
   if (n_max == 0u) return;
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
@@ -1012,7 +1017,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   const f3 obj_bmin = mk3(uni(obj->bmin[0]), uni(obj->bmin[1]), uni(obj->bmin[2]));
   const f3 obj_bmax = mk3(uni(obj->bmax[0]), uni(obj->bmax[1]), uni(obj->bmax[2]));
   BatchFeed feed;
-  feed.init(counters, bi, bounce, work_slot, sc.static_eighths);
+  feed.init(counters, bi, bounce, work_slot, sc.static_eighths, listed);
   uint32_t priv_next = 0u, priv_end = 0u;
 
   bool active = false;
@@ -1513,9 +1518,9 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
 template <bool kCount, bool kFirst>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES)))
 void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce, int work_slot,
-                 DeviceCounters* counters, uint32_t* slow_list, const uint32_t* order, DBatchInfo bi)
+                 DeviceCounters* counters, uint32_t* slow_list, const uint32_t* order, DBatchInfo bi, int listed)
 {
-  traverse4_walk<kCount, kFirst>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+  traverse4_walk<kCount, kFirst>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed != 0);
   // Epilogue: every wavefront signs off; the last one redoes the rays that were set aside.  The list entries were
   // written with agent-scope atomic stores; waiting for this wavefront's own stores before the sign-off and reading
   // the list with agent-scope loads orders them without a full L2 write-back per wavefront.
@@ -1537,9 +1542,16 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 // handing on the closest hit in the hit record.  (The run that ENDS the list -- or is the whole list -- is part of
 // the kernel that ends the bounce.)  (Taking the sphere runs into the traversal kernel instead was tried in round 2: inlined or as a
 // call, their temporaries pushed loop-carried state of the walk into scratch, with reloads inside its hot loop.)
-template <bool kFirst>
+// kFilter: the launch is followed by a traversal launch over the mesh objects [filt_begin, filt_end).  A ray that SURELY
+// misses the world boxes of all of them (the same test with the same margin by which that launch skips an instance,
+// traverse4m_walk::begin_object), or whose boxes all start beyond the closest hit so far, has nothing to do there: only
+// the others are put on the work list (batch-global slots, DeviceCounters::list_count per frame; their order is
+// irrelevant -- results are written per slot), and the traversal launch fetches its rays through that list.  In the
+// Cornell-box scenes most rays of most bounces never come near the meshes.
+template <bool kFirst, bool kFilter>
 __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
-                                                 int bounce, DeviceCounters* counters, DBatchInfo bi)
+                                                 int bounce, DeviceCounters* counters, DBatchInfo bi, uint32_t filt_begin,
+                                                 uint32_t filt_end, uint32_t* worklist)
 {
   const uint32_t frame = blockIdx.y;  // see DBatchInfo
   paths.o4 += (size_t)frame * bi.stride;
@@ -1560,6 +1572,29 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
   if (changed) store_hit(hits, s, rec);
   else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
+  if (kFilter) {
+    const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+    bool may_hit = !finite_f(winv.x + winv.y + winv.z);  // (a degenerate direction is the traversal launch's business)
+    for (uint32_t i = filt_begin; i < filt_end && !may_hit; ++i) {
+      const DObject* o = sc.objects + i;
+      const f3 a0 = (ld3(o->bmin) - ray.o) * winv, a1 = (ld3(o->bmax) - ray.o) * winv;
+      const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+      const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+      const bool surely_missed = finite_f(wn) && finite_f(wf) && (wn - wf) > 4e-6f * (fabsf(wf) + fabsf(wn));
+      // the box starts beyond the closest hit so far (ray.tmax; a mesh hit needs t <= t_max): with the margin of the
+      // reciprocals, and only for a box in front of the origin
+      const bool beyond = finite_f(wn) && wn > 0.0f && wn * (1.0f - 8e-6f) > ray.tmax;
+      may_hit = !(surely_missed || beyond);
+    }
+    const uint64_t listed = __ballot(may_hit);
+    if (listed != 0ull) {
+      uint32_t base = 0u;
+      const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;  // (the wavefront's first lane inside the live range)
+      if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&counters->list_count, (uint32_t)__popcll(listed));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+      if (may_hit) worklist[(size_t)frame * bi.stride + base + rank_below(listed)] = frame * bi.stride + s;
+    }
+  }
 }
 
 // The end of a bounce's closest-hit stage: the sphere run that ends the object list (if any) and the live count of
@@ -2490,11 +2525,21 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
   else hipLaunchKernelGGL(k_trace<false>, dim3(div_up(max_paths, kWave)), dim3(kWave), 0, s, scene, paths, hits, bounce, counters);
 }
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
-                    uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi)
+                    uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi, uint32_t filt_begin,
+                    uint32_t filt_end, uint32_t* worklist)
 {
   const dim3 grid(div_up(max_paths, 256u), bi.count), block(256);
-  if (first) hipLaunchKernelGGL((k_spheres<true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi);
-  else hipLaunchKernelGGL((k_spheres<false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi);
+#define PT_SPHERES(FIRST, FILTER)                                                                                              \
+  hipLaunchKernelGGL((k_spheres<FIRST, FILTER>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi, \
+                     filt_begin, filt_end, worklist)
+  if (worklist && filt_begin < filt_end) {
+    if (first) PT_SPHERES(true, true);
+    else PT_SPHERES(false, true);
+  } else {
+    if (first) PT_SPHERES(true, false);
+    else PT_SPHERES(false, false);
+  }
+#undef PT_SPHERES
 }
 void launch_tail_count(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                        DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts, DeviceCounters* counters,
@@ -2517,28 +2562,28 @@ void launch_scan(hipStream_t s, int bounce, bool last_bounce, const uint32_t* ch
 }
 void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                          DHits hits, int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                         uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi)
+                         uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi, bool listed)
 {
   const dim3 grid(waves), block(kWave);
   if (count_tests) {
-    if (first) hipLaunchKernelGGL((k_traverse4m<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-    else hipLaunchKernelGGL((k_traverse4m<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    if (first) hipLaunchKernelGGL((k_traverse4m<true, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
+    else hipLaunchKernelGGL((k_traverse4m<true, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
   } else {
-    if (first) hipLaunchKernelGGL((k_traverse4m<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-    else hipLaunchKernelGGL((k_traverse4m<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    if (first) hipLaunchKernelGGL((k_traverse4m<false, true>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
+    else hipLaunchKernelGGL((k_traverse4m<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
   }
 }
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
-                     uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi)
+                     uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi, bool listed)
 {
   const dim3 grid(waves), block(kWave);
   if (count_tests) {
-    if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-    else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
+    else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
   } else {
-    if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
-    else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi);
+    if (first) hipLaunchKernelGGL((k_traverse4<false, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
+    else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
   }
 }
 void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHits hits, uint32_t max_paths,

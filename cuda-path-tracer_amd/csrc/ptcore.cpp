@@ -86,6 +86,7 @@ struct ptc_ctx {
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
     uint32_t* order = nullptr;      // ... and the order in which the traversal lanes pick them up
+    uint32_t* worklist = nullptr;   // "filter_rays": the rays of the next traversal launch that may hit one of its objects (k_spheres)
     uint2* spill = nullptr;         // traversal stack overflow area of this slot's launches (DScene::spill)
     size_t spill_elems = 0;
     DFrame stage{};
@@ -179,6 +180,7 @@ struct ptc_ctx {
   // never waits for them, they only size the traversal launches
   uint32_t est_live[kMaxBounces + 1] = {};
   bool est_valid = false;
+  bool filter_rays = true;    // "filter_rays": a sphere run in front of a mesh launch also lists the rays that launch has to walk
   bool fused_shade = true;    // "fused_shade": the end of a bounce in one pass (k_shade_fused); 0: k_tail_count -> k_scan -> k_shade
   int ray_sort = 0;           // "ray_sort": 1 = traversal lanes pick their rays up grouped by direction octant (bounces >= 1)
   int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2
@@ -938,6 +940,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     sl.shade_epoch = 0;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_stack, (size_t)kStackDepth * kWave)) return rc;
+    if (int rc = dev_alloc(ctx, pool, &sl.worklist, BP)) return rc;
     if (ctx->ray_sort) {
       if (int rc = dev_alloc(ctx, pool, &sl.octs, BP)) return rc;
       if (int rc = dev_alloc(ctx, pool, &sl.order, BP)) return rc;
@@ -1092,6 +1095,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
   if (std::strcmp(name, "layout_on_device") == 0) {
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "layout_on_device must be 0 or 1");
     ctx->layout_on_device = value != 0;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "filter_rays") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "filter_rays must be 0 or 1");
+    ctx->filter_rays = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "fused_shade") == 0) {
@@ -1276,14 +1284,6 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     // closest hit = the object list walked by the launches of TraceLaunch
     for (size_t k = 0; k < ctx->launches.size(); ++k) {
       const auto& l = ctx->launches[k];
-      if (l.pre_begin < l.pre_end) {
-        launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi);
-        wrote = true;
-      }
-      ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
-      if (int rc = timed_begin(tl)) return rc;
-      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
-      scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
       // a run of objects that instantiate the same mesh, with nothing between them, is walked by ONE launch: a lane
       // keeps its ray and takes the instances in turn (k_traverse4m; "merge_instances")
       size_t run = 1;
@@ -1292,14 +1292,27 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
                ctx->launches[k + run].mesh == l.mesh + (uint32_t)run &&
                ctx->object_mesh[ctx->launches[k + run].mesh] == ctx->object_mesh[l.mesh])
           ++run;
+      // a sphere run in front of the launch reads every ray anyway: it also lists the rays that may hit one of the launch's
+      // objects at all ("filter_rays"), and the launch fetches through that list
+      const bool listed = ctx->filter_rays && l.pre_begin < l.pre_end && !sorted && ctx->trace_variant == 3;
+      if (l.pre_begin < l.pre_end) {
+        launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi,
+                       listed ? l.mesh : 0u, listed ? l.mesh + (uint32_t)run : 0u, listed ? sl.worklist : nullptr);
+        wrote = true;
+      }
+      ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
+      if (int rc = timed_begin(tl)) return rc;
+      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
+      scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
+      const uint32_t* pick = listed ? sl.worklist : (sorted ? sl.order : nullptr);
       if (run > 1) {
         launch_traverse_run(sl.stream, scene, l.mesh, l.mesh + (uint32_t)run, !wrote, in, sl.hits, bounce, sl.work_slot++ % kWorkSlots, sl.counters,
-                            ctx->count_tests, waves, sl.slow_list, sorted ? sl.order : nullptr, sl.bi);
+                            ctx->count_tests, waves, sl.slow_list, pick, sl.bi, listed);
         k += run - 1;
       } else {
         const int kernel = ctx->trace_variant;
         launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++ % kWorkSlots, sl.counters, ctx->count_tests, waves,
-                        sl.slow_list, sorted ? sl.order : nullptr, kernel, sl.bi);
+                        sl.slow_list, pick, kernel, sl.bi, listed);
       }
       wrote = true;
       if (int rc = timed_end(tl)) return rc;
