@@ -233,6 +233,11 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "layout_on_device" 1 (default): the traversal layouts (collapsed four-wide tree, leaf order, per-instance
  *                      triangle records) are derived on the GPU; 0: on the host.  Same bytes either way
  *                      (ptc_download_layout); a caller's BVH that is not numbered depth by depth goes to the host
+ *   "fused_shade"      1 (default): the end of a bounce -- trailing sphere run, material, stable compaction, final gather -- is
+ *                      ONE kernel (tiles by ticket, decoupled look-back; a bounded wait reports PTC_ERR_HIP from ptc_get_stats
+ *                      instead of ever hanging); 0: three kernels (count, scan, shade)
+ *   "filter_rays"      1 (default): a sphere run in front of a mesh launch also lists the rays that may hit one of the launch's
+ *                      world boxes at all, and the launch walks only those; 0: every live ray is fetched by the launch
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
