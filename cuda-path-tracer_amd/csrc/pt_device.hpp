@@ -247,8 +247,11 @@ void launch_instance_triangles(hipStream_t stream, const m4& m, const float* d_p
                                const uint32_t* d_tri_order, uint32_t triangles, float4* d_out);
 
 // ---- launch interface (implemented in pt_kernels.hip) ----
+// filt_begin < filt_end and worklist != null: the bounce's first launch is a traversal launch over the mesh objects
+// [filt_begin, filt_end); raygen lists the rays that may hit them and writes the miss record of the others into `hits`
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
-                   DPaths paths, DeviceCounters* counters);
+                   DPaths paths, DeviceCounters* counters, const DObject* objects = nullptr, uint32_t filt_begin = 0u,
+                   uint32_t filt_end = 0u, uint32_t* worklist = nullptr, DHits hits = DHits{nullptr, nullptr});
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   DeviceCounters* counters, bool count_tests, int variant);

@@ -636,37 +636,115 @@ __device__ __forceinline__ void generate_ray(const DCamera& cam, float fx, float
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// "filter_rays": may this ray hit one of the mesh objects [filt_begin, filt_end) of the traversal launch that follows?
+// No, if it SURELY misses the world boxes of all of them (the same test with the same margin by which that launch skips
+// an instance, traverse4m_walk::begin_object) or every box starts beyond the closest hit so far (tmax; a mesh hit needs
+// t <= t_max).  A degenerate direction is the traversal launch's business (yes).
+__device__ __forceinline__ bool may_hit_boxes(const DObject* objects, uint32_t filt_begin, uint32_t filt_end, const f3 o, const f3 d,
+                                              const float tmax)
+{
+  const f3 winv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  bool may_hit = !finite_f(winv.x + winv.y + winv.z);
+  for (uint32_t i = filt_begin; i < filt_end && !may_hit; ++i) {
+    const DObject* ob = objects + i;
+    const f3 a0 = (ld3(ob->bmin) - o) * winv, a1 = (ld3(ob->bmax) - o) * winv;
+    const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+    const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+    const bool surely_missed = finite_f(wn) && finite_f(wf) && (wn - wf) > 4e-6f * (fabsf(wf) + fabsf(wn));
+    // (with the margin of the reciprocals, and only for a box in front of the origin)
+    const bool beyond = finite_f(wn) && wn > 0.0f && wn * (1.0f - 8e-6f) > tmax;
+    may_hit = !(surely_missed || beyond);
+  }
+  return may_hit;
+}
+// ... and the rays go on the launch's work list (batch-global slots, DeviceCounters::list_count per frame; the order is
+// irrelevant -- results are written per slot).  A workgroup of 256 threads lists up to kListPer x 256 slots (thread t: slots
+// block_first + j * 256 + t, bit j of may_mask) with ONE atomic: an atomic per wavefront on the frame's counter line --
+// 648,000 of them per bounce of a 20-frame batch -- was a millisecond of serialised round trips (measured).
+// Every thread of the workgroup must call this.
+constexpr int kListPer = 4;
+__device__ __forceinline__ void list_rays(uint32_t may_mask, uint32_t* worklist, DeviceCounters* counters, size_t frame_base,
+                                          uint32_t block_first)
+{
+  __shared__ uint32_t s_list_cnt[kListPer * 4];
+  __shared__ uint32_t s_list_base;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t rank[kListPer];
+#pragma unroll
+  for (int j = 0; j < kListPer; ++j) {
+    const uint64_t m = __ballot((may_mask >> j & 1u) != 0u);
+    rank[j] = rank_below(m);
+    if ((threadIdx.x & 63u) == 0u) s_list_cnt[j * 4 + (int)wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t total = 0u;
+#pragma unroll
+    for (int k = 0; k < kListPer * 4; ++k) total += s_list_cnt[k];
+    s_list_base = total ? atomicAdd(&counters->list_count, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t at = s_list_base;
+#pragma unroll
+  for (int j = 0; j < kListPer; ++j) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = s_list_cnt[j * 4 + w];
+      if ((uint32_t)w == wave && (may_mask >> j & 1u))
+        worklist[frame_base + at + rank[j]] = (uint32_t)frame_base + block_first + (uint32_t)j * 256u + threadIdx.x;
+      at += c;
+    }
+  }
+}
+
 // raygen_kernel, ray_gen.cu:11-32.  Slot s of this context holds pixel band_pixel(band, s).
+// kFilter ("filter_rays"): the bounce's first launch is a traversal launch over the mesh objects [filt_begin, filt_end)
+// (no sphere run in front of it): the rays that may hit one of their world boxes go on its work list, the others get
+// their miss record here (what that launch would have written for them) -- the sky pixels of an outdoor scene never
+// reach the traversal kernel.
+template <bool kFilter>
 __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DBand band, uint32_t pix_count,
-                                                DPaths paths, DeviceCounters* counters)
+                                                DPaths paths, DeviceCounters* counters, const DObject* objects, uint32_t filt_begin,
+                                                uint32_t filt_end, uint32_t* worklist, DHits hits)
 {
   const uint32_t frame = blockIdx.y;  // see DBatchInfo
   const DCamera& cam = cams.c[frame];
   const uint32_t iteration = bi.iteration[frame];
   paths.o4 += (size_t)frame * bi.stride;
   paths.d4 += (size_t)frame * bi.stride;
-  paths.t4 += (size_t)frame * bi.stride;
   counters += frame;
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s == 0u) {
-    counters->live[0] = pix_count;
-    counters->list_count = 0u;
-  }
-  if (blockIdx.x == 0u)  // fetch cursors of this frame's persistent traversal launches
+  const uint32_t block_first = blockIdx.x * (256u * kListPer);  // a workgroup generates kListPer x 256 consecutive slots
+  if (blockIdx.x == 0u) {
+    // (list_count is NOT touched here: other workgroups of this very launch may be adding to it; it is zero at
+    // allocation and the traversal launch that consumes a list zeroes it in its epilogue)
+    if (threadIdx.x == 0u) counters->live[0] = pix_count;
+    // fetch cursors of this frame's persistent traversal launches
     for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0][0])[i * 32u] = 0u;
-  if (s >= pix_count) return;
-  const uint32_t pixel = band_pixel(band, s);
-  const uint32_t x = pixel % cam.width, y = pixel / cam.width;
-  Minstd rng;
-  rng.seed(path_seed(pixel, iteration));
-  const float fx = (float)x + rng.uniform();
-  const float fy = (float)y + rng.uniform();
-  f3 o, d;
-  generate_ray(cam, fx, fy, o, d);
-  stnt(&paths.o4[s], make_float4(o.x, o.y, o.z, __uint_as_float(pixel)));
-  stnt(&paths.d4[s], make_float4(d.x, d.y, d.z, 0.0f));
-  // (the throughput of a primary ray is (1, 1, 1), ray_gen.cu:25: the shade kernels know that at bounce 0 and neither
-  // is it written here nor read there -- 32 bytes per pixel and frame less)
+  }
+  uint32_t may_mask = 0u;
+#pragma unroll
+  for (int j = 0; j < kListPer; ++j) {
+    const uint32_t s = block_first + (uint32_t)j * 256u + threadIdx.x;
+    if (s >= pix_count) continue;
+    const uint32_t pixel = band_pixel(band, s);
+    const uint32_t x = pixel % cam.width, y = pixel / cam.width;
+    Minstd rng;
+    rng.seed(path_seed(pixel, iteration));
+    const float fx = (float)x + rng.uniform();
+    const float fy = (float)y + rng.uniform();
+    f3 o, d;
+    generate_ray(cam, fx, fy, o, d);
+    stnt(&paths.o4[s], make_float4(o.x, o.y, o.z, __uint_as_float(pixel)));
+    stnt(&paths.d4[s], make_float4(d.x, d.y, d.z, 0.0f));
+    // (the throughput of a primary ray is (1, 1, 1), ray_gen.cu:25: the shade kernels know that at bounce 0 and neither
+    // is it written here nor read there -- 32 bytes per pixel and frame less)
+    if (kFilter) {
+      const bool may_hit = may_hit_boxes(objects, filt_begin, filt_end, o, d, FLT_MAX);
+      if (!may_hit) stnt(&hits.tp[(size_t)frame * bi.stride + s], make_float4(-1.0f, 0.f, 0.f, 0.f));
+      may_mask |= may_hit ? 1u << j : 0u;
+    }
+  }
+  if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, block_first);
 }
 
 __device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
@@ -1560,41 +1638,26 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   hits.nm += (size_t)frame * bi.stride;
   counters += frame;
   const uint32_t n = counters->live[bounce];
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= n) return;
-  Ray ray = load_ray(paths, s);
-  if (!kFirst) {
-    const float carried = ldnt(&hits.tp[s]).x;
-    if (carried >= 0.0f) ray.tmax = carried;
-  }
-  Hit rec;
-  bool changed = false;
-  sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
-  if (changed) store_hit(hits, s, rec);
-  else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
-  if (kFilter) {
-    const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
-    bool may_hit = !finite_f(winv.x + winv.y + winv.z);  // (a degenerate direction is the traversal launch's business)
-    for (uint32_t i = filt_begin; i < filt_end && !may_hit; ++i) {
-      const DObject* o = sc.objects + i;
-      const f3 a0 = (ld3(o->bmin) - ray.o) * winv, a1 = (ld3(o->bmax) - ray.o) * winv;
-      const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
-      const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
-      const bool surely_missed = finite_f(wn) && finite_f(wf) && (wn - wf) > 4e-6f * (fabsf(wf) + fabsf(wn));
-      // the box starts beyond the closest hit so far (ray.tmax; a mesh hit needs t <= t_max): with the margin of the
-      // reciprocals, and only for a box in front of the origin
-      const bool beyond = finite_f(wn) && wn > 0.0f && wn * (1.0f - 8e-6f) > ray.tmax;
-      may_hit = !(surely_missed || beyond);
+  const uint32_t block_first = blockIdx.x * (256u * kListPer);  // a workgroup tests kListPer x 256 consecutive slots
+  if (block_first >= n) return;
+  uint32_t may_mask = 0u;
+#pragma unroll 1
+  for (int j = 0; j < kListPer; ++j) {
+    const uint32_t s = block_first + (uint32_t)j * 256u + threadIdx.x;
+    if (s >= n) continue;
+    Ray ray = load_ray(paths, s);
+    if (!kFirst) {
+      const float carried = ldnt(&hits.tp[s]).x;
+      if (carried >= 0.0f) ray.tmax = carried;
     }
-    const uint64_t listed = __ballot(may_hit);
-    if (listed != 0ull) {
-      uint32_t base = 0u;
-      const int leader = __ffsll((unsigned long long)__ballot(true)) - 1;  // (the wavefront's first lane inside the live range)
-      if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&counters->list_count, (uint32_t)__popcll(listed));
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-      if (may_hit) worklist[(size_t)frame * bi.stride + base + rank_below(listed)] = frame * bi.stride + s;
-    }
+    Hit rec;
+    bool changed = false;
+    sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
+    if (changed) store_hit(hits, s, rec);
+    else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
+    if (kFilter && may_hit_boxes(sc.objects, filt_begin, filt_end, ray.o, ray.d, ray.tmax)) may_mask |= 1u << j;
   }
+  if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, block_first);
 }
 
 // The end of a bounce's closest-hit stage: the sphere run that ends the object list (if any) and the live count of
@@ -2507,10 +2570,15 @@ __global__ void k_selftest(const float* a, const float* b, uint32_t n, float* ou
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
-                   DPaths paths, DeviceCounters* counters)
+                   DPaths paths, DeviceCounters* counters, const DObject* objects, uint32_t filt_begin, uint32_t filt_end,
+                   uint32_t* worklist, DHits hits)
 {
-  hipLaunchKernelGGL(k_raygen, dim3(div_up(pix_count, 256u), bi.count), dim3(256), 0, s, cams, bi, band, pix_count,
-                     paths, counters);
+  const dim3 grid(div_up(pix_count, 256u * kListPer), bi.count), block(256);
+  if (worklist && filt_begin < filt_end)
+    hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, filt_begin, filt_end,
+                       worklist, hits);
+  else
+    hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, 0u, 0u, worklist, hits);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   DeviceCounters* counters, bool count_tests, int variant)
@@ -2528,7 +2596,7 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi, uint32_t filt_begin,
                     uint32_t filt_end, uint32_t* worklist)
 {
-  const dim3 grid(div_up(max_paths, 256u), bi.count), block(256);
+  const dim3 grid(div_up(max_paths, 256u * kListPer), bi.count), block(256);
 #define PT_SPHERES(FIRST, FILTER)                                                                                              \
   hipLaunchKernelGGL((k_spheres<FIRST, FILTER>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi, \
                      filt_begin, filt_end, worklist)

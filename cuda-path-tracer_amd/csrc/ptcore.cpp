@@ -86,6 +86,7 @@ struct ptc_ctx {
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
     uint32_t* order = nullptr;      // ... and the order in which the traversal lanes pick them up
+    bool first_listed = false;      // ... k_raygen has listed the rays of bounce 0's first traversal launch (this batch)
     uint32_t* worklist = nullptr;   // "filter_rays": the rays of the next traversal launch that may hit one of its objects (k_spheres)
     uint2* spill = nullptr;         // traversal stack overflow area of this slot's launches (DScene::spill)
     size_t spill_elems = 0;
@@ -1211,6 +1212,20 @@ uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce)
 }
 
 // Enqueue raygen for `count` consecutive iterations on the next slot (round robin) and make it the active batch.
+// launches [k, k + run) of the plan are one traversal launch: consecutive objects that instantiate the same mesh, with
+// nothing between them (k_traverse4m; "merge_instances")
+size_t launch_run(const ptc_ctx* ctx, size_t k)
+{
+  size_t run = 1;
+  const auto& l = ctx->launches[k];
+  if (ctx->trace_variant == 3 && ctx->merge_instances)
+    while (k + run < ctx->launches.size() && ctx->launches[k + run].pre_begin == ctx->launches[k + run].pre_end &&
+           ctx->launches[k + run].mesh == l.mesh + (uint32_t)run &&
+           ctx->object_mesh[ctx->launches[k + run].mesh] == ctx->object_mesh[l.mesh])
+      ++run;
+  return run;
+}
+
 int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
 {
   const int single_slots = (int)ctx->slots.size() - ctx->big_slots;
@@ -1241,7 +1256,13 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
     cams.c[k] = items[k].cam;
     sl.bi.iteration[k] = items[k].iteration;
   }
-  launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters);
+  // "filter_rays" at bounce 0: when the bounce opens with a traversal launch (no sphere run in front of the first mesh),
+  // raygen lists the rays that may hit that launch's world boxes and writes the others' miss records itself
+  sl.first_listed = ctx->filter_rays && ctx->trace_variant == 3 && !ctx->launches.empty() &&
+                    ctx->launches[0].pre_begin == ctx->launches[0].pre_end;
+  const uint32_t first_mesh = sl.first_listed ? ctx->launches[0].mesh : 0u;
+  launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters, ctx->scene.objects, first_mesh,
+                sl.first_listed ? first_mesh + (uint32_t)launch_run(ctx, 0) : 0u, sl.first_listed ? sl.worklist : nullptr, sl.hits);
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->active_slot = f;
   return PTC_OK;
@@ -1284,20 +1305,14 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     // closest hit = the object list walked by the launches of TraceLaunch
     for (size_t k = 0; k < ctx->launches.size(); ++k) {
       const auto& l = ctx->launches[k];
-      // a run of objects that instantiate the same mesh, with nothing between them, is walked by ONE launch: a lane
-      // keeps its ray and takes the instances in turn (k_traverse4m; "merge_instances")
-      size_t run = 1;
-      if (ctx->trace_variant == 3 && ctx->merge_instances)
-        while (k + run < ctx->launches.size() && ctx->launches[k + run].pre_begin == ctx->launches[k + run].pre_end &&
-               ctx->launches[k + run].mesh == l.mesh + (uint32_t)run &&
-               ctx->object_mesh[ctx->launches[k + run].mesh] == ctx->object_mesh[l.mesh])
-          ++run;
+      const size_t run = launch_run(ctx, k);
       // a sphere run in front of the launch reads every ray anyway: it also lists the rays that may hit one of the launch's
       // objects at all ("filter_rays"), and the launch fetches through that list
-      const bool listed = ctx->filter_rays && l.pre_begin < l.pre_end && !sorted && ctx->trace_variant == 3;
+      const bool by_spheres = ctx->filter_rays && l.pre_begin < l.pre_end && !sorted && ctx->trace_variant == 3;
+      const bool listed = by_spheres || (bounce == 0 && k == 0 && sl.first_listed);  // (bounce 0's first launch: listed by k_raygen)
       if (l.pre_begin < l.pre_end) {
         launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi,
-                       listed ? l.mesh : 0u, listed ? l.mesh + (uint32_t)run : 0u, listed ? sl.worklist : nullptr);
+                       by_spheres ? l.mesh : 0u, by_spheres ? l.mesh + (uint32_t)run : 0u, by_spheres ? sl.worklist : nullptr);
         wrote = true;
       }
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
