@@ -124,11 +124,16 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
     profiles/ were taken on THIS scene (config 3); otherwise traffic / valu are null."""
     scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
     rays = sum(paths_timed)
+    # "filter_rays": a bounce whose traversal launch fetched through a work list walked only the listed rays; the others'
+    # closest-hit queries were answered by the kernel that built the list (their world-box test).  The launch is priced with
+    # the rays it read and wrote, the frame with all queries.
+    listed = prof.get("listed_rays") or [0] * MB
+    walked = [int(listed[b]) if listed[b] else int(paths_timed[b]) for b in range(MB)]
     nodes = sum(scale[b] * counted["node_visits"][b] for b in range(MB))
     boxes = sum(scale[b] * counted["box_tests"][b] for b in range(MB))
     tris = sum(scale[b] * counted["tri_tests"][b] for b in range(MB))
-    alg_bytes = rays * 52 + nodes * 32 + tris * 48          # SURVEY 8(d): 32 B per node visit
-    req_bytes = rays * 52 + nodes * 64 + tris * 48          # this layout: 64-byte node records
+    alg_bytes = sum(walked) * 52 + nodes * 32 + tris * 48   # SURVEY 8(d): 32 B per node visit
+    req_bytes = sum(walked) * 52 + nodes * 64 + tris * 48   # this layout: 64-byte node records
     trace_ms = sum(prof["trace_ms"])
     launches = sum(prof["trace_launches"])
     achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
@@ -152,6 +157,7 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
         "launches": launches, "avg_launch_us": round(trace_ms * 1e3 / max(launches, 1), 2),
         "alg_bytes_per_launch": round(alg_bytes / max(launches, 1)),
         "alg_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
+        "rays_walked_by_the_launches": sum(walked), "rays_answered_by_the_list_builder": int(rays - sum(walked)),
         "requested_bytes_per_launch": round(req_bytes / max(launches, 1)),
         "achieved_requested": round(req_bytes / (trace_ms * 1e-3) / 1e9, 2) if trace_ms > 0 else 0.0,
         "frac_requested": round(req_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if trace_ms > 0 else 0.0,
@@ -169,9 +175,9 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
         if not paths_timed[b]:
             continue
         nb, tb = scale[b] * counted["node_visits"][b], scale[b] * counted["tri_tests"][b]
-        bytes_b = paths_timed[b] * 52 + nb * 32 + tb * 48
+        bytes_b = walked[b] * 52 + nb * 32 + tb * 48
         ms_b = prof["trace_ms"][b]
-        per_bounce.append({"bounce": b, "rays": int(paths_timed[b]), "trace_ms": round(ms_b, 3), "launches": int(prof["trace_launches"][b]),
+        per_bounce.append({"bounce": b, "rays": int(paths_timed[b]), "rays_walked": walked[b], "trace_ms": round(ms_b, 3), "launches": int(prof["trace_launches"][b]),
                            "node_visits_per_ray": round(nb / paths_timed[b], 2), "tri_tests_per_ray": round(tb / paths_timed[b], 2),
                            "ns_per_ray": round(ms_b * 1e6 / paths_timed[b], 3) if ms_b > 0 else None,
                            "frac": round(bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_b > 0 else None})

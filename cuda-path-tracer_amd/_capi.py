@@ -90,7 +90,7 @@ class ptc_profile(C.Structure):
     _fields_ = [("paths", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("box_tests", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
                 ("tri_tests", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("trace_ms", C.c_double * PTC_MAX_BOUNCES_CAP),
                 ("trace_launches", C.c_uint32 * PTC_MAX_BOUNCES_CAP), ("max_box_tests", C.c_uint32 * PTC_MAX_BOUNCES_CAP),
-                ("max_ray_cycles", C.c_uint32 * PTC_MAX_BOUNCES_CAP), ("max_wave_cycles", C.c_uint32 * PTC_MAX_BOUNCES_CAP),
+                ("listed_rays", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
                 ("slow_rays", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
                 ("node_visits", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("denoise_ms", C.c_double),
                 ("denoise_passes", C.c_uint32), ("reserved", C.c_uint32)]

@@ -192,8 +192,7 @@ struct DeviceCounters {
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
   unsigned long long tri_tests[kMaxBounces];
   uint32_t max_box_tests[kMaxBounces];        // longest single traversal (box tests of one ray), instrumented runs
-  uint32_t max_ray_cycles[kMaxBounces];       // longest single traversal in shader clocks (s_memtime), instrumented runs
-  uint32_t max_wave_cycles[kMaxBounces];      // longest-lived persistent wavefront, instrumented runs
+  unsigned long long listed_rays[kMaxBounces];  // rays the traversal launches fetched through a work list (frame 0's block: whole batch)
   unsigned long long slow_rays[kMaxBounces];  // rays redone exactly (redo_slow_rays)
   unsigned long long node_visits[kMaxBounces];  // BVH node records fetched by the closest-hit kernels, instrumented runs
   // ray-fetch cursors of the persistent traversal launches, one per image region, each on its own 128-byte

@@ -1042,6 +1042,13 @@ struct BatchFeed {
 #endif
 
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
+  return v;
+}
+
 // End of a persistent traversal launch, run by its LAST wavefront (after the exact redo): the bookkeeping of the next
 // launch on this stream starts from zero -- the redo list, the sign-off counter and the fetch cursors of this launch's
 // set for every frame of the batch (plain stores: the next launch starts after this one has completed).
@@ -1049,8 +1056,15 @@ __device__ __forceinline__ void launch_epilogue(DeviceCounters* counters, int bo
                                                 const DBatchInfo& bi)
 {
   for (uint32_t i = threadIdx.x; i < bi.count * 8u; i += (uint32_t)kWave) counters[i >> 3].work[work_slot][i & 7u][0] = 0u;
-  for (uint32_t f = threadIdx.x; f < bi.count; f += (uint32_t)kWave) counters[f].list_count = 0u;  // (a work list is used once)
+  // (a work list is used once; what was on it goes into the profile)
+  uint32_t listed = 0u;
+  for (uint32_t f = threadIdx.x; f < bi.count; f += (uint32_t)kWave) {
+    listed += counters[f].list_count;
+    counters[f].list_count = 0u;
+  }
+  listed = wave_sum(listed);
   if (threadIdx.x == 0u) {
+    counters->listed_rays[bounce] += listed;
     counters->slow_rays[bounce] += redone;
     counters->slow_count = 0u;
     counters->waves_done = 0u;
@@ -1862,12 +1876,6 @@ constexpr int kFuseK = PT_FUSE_K;
 constexpr uint32_t kFuseTile = 256u * kFuseK;
 constexpr unsigned long long kDescAggregate = 1ull << 32, kDescPrefix = 2ull << 32;
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
-  return v;
-}
 
 // exclusive prefix of `tile` (survivors of tiles [0, tile)), by the calling wavefront; every lane returns it
 __device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc, uint32_t tile, uint32_t epoch, uint32_t* flags)

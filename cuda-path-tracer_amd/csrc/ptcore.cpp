@@ -1900,8 +1900,7 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
       out->box_tests[b] += host.box_tests[b];
       out->tri_tests[b] += host.tri_tests[b];
       out->max_box_tests[b] = std::max(out->max_box_tests[b], host.max_box_tests[b]);
-      out->max_ray_cycles[b] = std::max(out->max_ray_cycles[b], host.max_ray_cycles[b]);
-      out->max_wave_cycles[b] = std::max(out->max_wave_cycles[b], host.max_wave_cycles[b]);
+      out->listed_rays[b] += host.listed_rays[b];
       out->slow_rays[b] += host.slow_rays[b];
       out->node_visits[b] += host.node_visits[b];
     }

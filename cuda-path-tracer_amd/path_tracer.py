@@ -280,8 +280,7 @@ class PathTracer:
                 "tri_tests": [int(x) for x in p.tri_tests[:n]], "trace_ms": [float(x) for x in p.trace_ms[:n]],
                 "trace_launches": [int(x) for x in p.trace_launches[:n]],
                 "max_box_tests": [int(x) for x in p.max_box_tests[:n]],
-                "max_ray_cycles": [int(x) for x in p.max_ray_cycles[:n]],
-                "max_wave_cycles": [int(x) for x in p.max_wave_cycles[:n]],
+                "listed_rays": [int(x) for x in p.listed_rays[:n]],
                 "slow_rays": [int(x) for x in p.slow_rays[:n]],
                 "node_visits": [int(x) for x in p.node_visits[:n]],
                 "denoise_ms": float(p.denoise_ms), "denoise_passes": int(p.denoise_passes)}

@@ -159,8 +159,7 @@ typedef struct ptc_profile {
   double trace_ms[PTC_MAX_BOUNCES_CAP];
   uint32_t trace_launches[PTC_MAX_BOUNCES_CAP];
   uint32_t max_box_tests[PTC_MAX_BOUNCES_CAP]; /* longest single traversal seen (counting runs) */
-  uint32_t max_ray_cycles[PTC_MAX_BOUNCES_CAP];  /* ... in shader clocks, and the longest-lived wavefront */
-  uint32_t max_wave_cycles[PTC_MAX_BOUNCES_CAP];
+  uint64_t listed_rays[PTC_MAX_BOUNCES_CAP]; /* rays the traversal launches fetched through a work list ("filter_rays"); 0: they walked all live rays */
   uint64_t slow_rays[PTC_MAX_BOUNCES_CAP];   /* rays redone with exact box decisions at the end of a traversal launch (always counted) */
   uint64_t node_visits[PTC_MAX_BOUNCES_CAP]; /* BVH node records fetched (counting runs): SURVEY 8(d)'s N_node */
   double denoise_ms;                         /* summed duration of the A-Trous passes (HIP events, while events are enabled) */
@@ -236,8 +235,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "fused_shade"      1 (default): the end of a bounce -- trailing sphere run, material, stable compaction, final gather -- is
  *                      ONE kernel (tiles by ticket, decoupled look-back; a bounded wait reports PTC_ERR_HIP from ptc_get_stats
  *                      instead of ever hanging); 0: three kernels (count, scan, shade)
- *   "filter_rays"      1 (default): a sphere run in front of a mesh launch also lists the rays that may hit one of the launch's
- *                      world boxes at all, and the launch walks only those; 0: every live ray is fetched by the launch
+ *   "filter_rays"      1 (default): the kernel in front of a mesh launch (a sphere run; ray generation at bounce 0) also lists the
+ *                      rays that may hit one of the launch's world boxes at all, and the launch walks only those
+ *                      (ptc_profile::listed_rays); 0: every live ray is fetched by the launch
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
