@@ -247,10 +247,13 @@ void launch_instance_triangles(hipStream_t stream, const m4& m, const float* d_p
 
 // ---- launch interface (implemented in pt_kernels.hip) ----
 // filt_begin < filt_end and worklist != null: the bounce's first launch is a traversal launch over the mesh objects
-// [filt_begin, filt_end); raygen lists the rays that may hit them and writes the miss record of the others into `hits`
+// [filt_begin, filt_end); raygen lists the rays that may hit them (in slot order: a look-back scan on the descriptors
+// tile_desc -- k_shade_fused's, tile_stride per frame -- under a launch epoch of its own) and writes the miss record of
+// the others into `hits`
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters, const DObject* objects = nullptr, uint32_t filt_begin = 0u,
-                   uint32_t filt_end = 0u, uint32_t* worklist = nullptr, DHits hits = DHits{nullptr, nullptr});
+                   uint32_t filt_end = 0u, uint32_t* worklist = nullptr, DHits hits = DHits{nullptr, nullptr},
+                   unsigned long long* tile_desc = nullptr, uint32_t tile_stride = 0u, uint32_t epoch = 0u);
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   DeviceCounters* counters, bool count_tests, int variant);
@@ -266,10 +269,11 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
 // first: nothing has written the hit records in this bounce yet
 // filt_begin < filt_end and worklist != null: also builds the work list of the traversal launch that follows over the mesh
 // objects [filt_begin, filt_end) (rays that surely miss all their world boxes are left out); that launch then gets
-// order = worklist, listed = true
+// order = worklist, listed = true.  (tile_desc, tile_stride, epoch: as for launch_raygen)
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi, uint32_t filt_begin = 0u,
-                    uint32_t filt_end = 0u, uint32_t* worklist = nullptr);
+                    uint32_t filt_end = 0u, uint32_t* worklist = nullptr, unsigned long long* tile_desc = nullptr,
+                    uint32_t tile_stride = 0u, uint32_t epoch = 0u);
 // a run [obj_begin, obj_end) of mesh objects of the SAME mesh in one launch (k_traverse4m): variant 3 only
 void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                          DHits hits, int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,

@@ -657,14 +657,42 @@ __device__ __forceinline__ bool may_hit_boxes(const DObject* objects, uint32_t f
   }
   return may_hit;
 }
-// ... and the rays go on the launch's work list (batch-global slots, DeviceCounters::list_count per frame; the order is
-// irrelevant -- results are written per slot).  A workgroup of 256 threads lists up to kListPer x 256 slots (thread t: slots
-// block_first + j * 256 + t, bit j of may_mask) with ONE atomic: an atomic per wavefront on the frame's counter line --
-// 648,000 of them per bounce of a 20-frame batch -- was a millisecond of serialised round trips (measured).
-// Every thread of the workgroup must call this.
+// ... and the rays go on the launch's work list (batch-global slots, DeviceCounters::list_count per frame) IN SLOT ORDER.
+// The order does not matter for the results (they are written per slot) but it decides what the traversal launch costs:
+// its wavefronts take the list in batches from cursors that move through it, so at any moment an XCD works on
+// neighbouring list entries.  With the entries in slot order those are neighbouring pixels and the part of the tree
+// they walk stays in the XCD's L2; with workgroups appending in the order they happened to finish (one atomicAdd each,
+// tried first) the fabric reads of bounce 0's launch were 13.6 GB per 20 frames instead of 2.1 GB (L2 hit rate 0.54
+// instead of 0.89; profiles/r03_worklist_order.txt).
+// So a workgroup's place in the list is the exclusive prefix of the counts of the workgroups before it, by the
+// decoupled look-back of k_shade_fused on the same descriptors (a launch of its own epoch) -- and for the same reason as
+// there a workgroup's tile is its TICKET, not its block index (list_tile).  A workgroup of 256 threads lists up to
+// kListPer x 256 slots (thread t: slots tile_first + j * 256 + t, bit j of may_mask); the last tile writes the frame's
+// total.  Every thread of the workgroup must call this.
 constexpr int kListPer = 4;
+struct DTileScan {
+  unsigned long long* desc;  // this frame's descriptors
+  uint32_t epoch;
+};
+__device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc, uint32_t tile, uint32_t epoch, uint32_t* flags);
+constexpr unsigned long long kDescAggregate = 1ull << 32, kDescPrefix = 2ull << 32;
+
+// the tile of this workgroup: tickets of the frame's counter, handed out in the order the workgroups start
+__device__ __forceinline__ uint32_t list_tile(DeviceCounters* counters, uint32_t workgroups_per_frame)
+{
+  __shared__ uint32_t s_list_tile;
+  if (threadIdx.x == 0u) {
+    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every workgroup of the frame has its ticket once the last one is out: the next launch starts from zero
+    if (t + 1u == workgroups_per_frame) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_list_tile = t;
+  }
+  __syncthreads();
+  return s_list_tile;
+}
+
 __device__ __forceinline__ void list_rays(uint32_t may_mask, uint32_t* worklist, DeviceCounters* counters, size_t frame_base,
-                                          uint32_t block_first)
+                                          uint32_t tile, uint32_t tiles, const DTileScan& scan)
 {
   __shared__ uint32_t s_list_cnt[kListPer * 4];
   __shared__ uint32_t s_list_base;
@@ -677,21 +705,34 @@ __device__ __forceinline__ void list_rays(uint32_t may_mask, uint32_t* worklist,
     if ((threadIdx.x & 63u) == 0u) s_list_cnt[j * 4 + (int)wave] = (uint32_t)__popcll(m);
   }
   __syncthreads();
-  if (threadIdx.x == 0u) {
-    uint32_t total = 0u;
+  if (wave == 0u) {
+    uint32_t agg = 0u;
 #pragma unroll
-    for (int k = 0; k < kListPer * 4; ++k) total += s_list_cnt[k];
-    s_list_base = total ? atomicAdd(&counters->list_count, total) : 0u;
+    for (int k = 0; k < kListPer * 4; ++k) agg += s_list_cnt[k];
+    const unsigned long long tag = (unsigned long long)scan.epoch << 34;
+    if (threadIdx.x == 0u)
+      __hip_atomic_store(&scan.desc[tile], tag | (tile == 0u ? kDescPrefix : kDescAggregate) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0u;
+    if (tile != 0u) {
+      excl = tile_lookback(scan.desc, tile, scan.epoch, &counters->flags);
+      if (threadIdx.x == 0u)
+        __hip_atomic_store(&scan.desc[tile], tag | kDescPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0u) {
+      s_list_base = excl;
+      if (tile + 1u == tiles) counters->list_count = excl + agg;
+    }
   }
   __syncthreads();
   uint32_t at = s_list_base;
+  const uint32_t tile_first = tile * (256u * (uint32_t)kListPer);
 #pragma unroll
   for (int j = 0; j < kListPer; ++j) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const uint32_t c = s_list_cnt[j * 4 + w];
       if ((uint32_t)w == wave && (may_mask >> j & 1u))
-        worklist[frame_base + at + rank[j]] = (uint32_t)frame_base + block_first + (uint32_t)j * 256u + threadIdx.x;
+        worklist[frame_base + at + rank[j]] = (uint32_t)frame_base + tile_first + (uint32_t)j * 256u + threadIdx.x;
       at += c;
     }
   }
@@ -705,18 +746,19 @@ __device__ __forceinline__ void list_rays(uint32_t may_mask, uint32_t* worklist,
 template <bool kFilter>
 __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DBand band, uint32_t pix_count,
                                                 DPaths paths, DeviceCounters* counters, const DObject* objects, uint32_t filt_begin,
-                                                uint32_t filt_end, uint32_t* worklist, DHits hits)
+                                                uint32_t filt_end, uint32_t* worklist, DHits hits, DTileScan scan, uint32_t tile_stride)
 {
-  const uint32_t frame = blockIdx.y;  // see DBatchInfo
+  const uint32_t frame = blockIdx.x % bi.count;  // see DBatchInfo; frame-fastest: neighbouring workgroups take their tickets on different lines
   const DCamera& cam = cams.c[frame];
   const uint32_t iteration = bi.iteration[frame];
   paths.o4 += (size_t)frame * bi.stride;
   paths.d4 += (size_t)frame * bi.stride;
   counters += frame;
-  const uint32_t block_first = blockIdx.x * (256u * kListPer);  // a workgroup generates kListPer x 256 consecutive slots
-  if (blockIdx.x == 0u) {
-    // (list_count is NOT touched here: other workgroups of this very launch may be adding to it; it is zero at
-    // allocation and the traversal launch that consumes a list zeroes it in its epilogue)
+  scan.desc += (size_t)frame * tile_stride;
+  const uint32_t tiles = gridDim.x / bi.count;
+  const uint32_t tile = kFilter ? list_tile(counters, tiles) : blockIdx.x / bi.count;
+  const uint32_t block_first = tile * (256u * kListPer);  // a workgroup generates kListPer x 256 consecutive slots
+  if (tile == 0u) {
     if (threadIdx.x == 0u) counters->live[0] = pix_count;
     // fetch cursors of this frame's persistent traversal launches
     for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0][0])[i * 32u] = 0u;
@@ -744,7 +786,7 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
       may_mask |= may_hit ? 1u << j : 0u;
     }
   }
-  if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, block_first);
+  if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, tile, tiles, scan);
 }
 
 __device__ __forceinline__ Ray load_ray(const DPaths& paths, uint32_t s)
@@ -1643,17 +1685,23 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 template <bool kFirst, bool kFilter>
 __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
                                                  int bounce, DeviceCounters* counters, DBatchInfo bi, uint32_t filt_begin,
-                                                 uint32_t filt_end, uint32_t* worklist)
+                                                 uint32_t filt_end, uint32_t* worklist, DTileScan scan, uint32_t tile_stride)
 {
-  const uint32_t frame = blockIdx.y;  // see DBatchInfo
+  const uint32_t frame = blockIdx.x % bi.count;  // see DBatchInfo; frame-fastest as in k_raygen
   paths.o4 += (size_t)frame * bi.stride;
   paths.d4 += (size_t)frame * bi.stride;
   hits.tp += (size_t)frame * bi.stride;
   hits.nm += (size_t)frame * bi.stride;
   counters += frame;
+  scan.desc += (size_t)frame * tile_stride;
   const uint32_t n = counters->live[bounce];
-  const uint32_t block_first = blockIdx.x * (256u * kListPer);  // a workgroup tests kListPer x 256 consecutive slots
-  if (block_first >= n) return;
+  const uint32_t tiles = (n + 256u * kListPer - 1u) / (256u * kListPer);
+  const uint32_t tile = kFilter ? list_tile(counters, gridDim.x / bi.count) : blockIdx.x / bi.count;
+  const uint32_t block_first = tile * (256u * kListPer);  // a workgroup tests kListPer x 256 consecutive slots
+  if (tile >= tiles) {
+    if (kFilter && tiles == 0u && tile == 0u && threadIdx.x == 0u) counters->list_count = 0u;  // nothing alive: an empty list
+    return;
+  }
   uint32_t may_mask = 0u;
 #pragma unroll 1
   for (int j = 0; j < kListPer; ++j) {
@@ -1671,7 +1719,7 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
     else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
     if (kFilter && may_hit_boxes(sc.objects, filt_begin, filt_end, ray.o, ray.d, ray.tmax)) may_mask |= 1u << j;
   }
-  if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, block_first);
+  if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, tile, tiles, scan);
 }
 
 // The end of a bounce's closest-hit stage: the sphere run that ends the object list (if any) and the live count of
@@ -1874,7 +1922,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 
 constexpr int kFuseK = PT_FUSE_K;
 constexpr uint32_t kFuseTile = 256u * kFuseK;
-constexpr unsigned long long kDescAggregate = 1ull << 32, kDescPrefix = 2ull << 32;
+static_assert(kFuseTile == 256u * kListPer, "k_raygen / k_spheres scan their work lists on k_shade_fused's tile descriptors");
 
 
 // exclusive prefix of `tile` (survivors of tiles [0, tile)), by the calling wavefront; every lane returns it
@@ -2579,14 +2627,16 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b;
 
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters, const DObject* objects, uint32_t filt_begin, uint32_t filt_end,
-                   uint32_t* worklist, DHits hits)
+                   uint32_t* worklist, DHits hits, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch)
 {
-  const dim3 grid(div_up(pix_count, 256u * kListPer), bi.count), block(256);
-  if (worklist && filt_begin < filt_end)
+  const dim3 grid(div_up(pix_count, 256u * kListPer) * bi.count), block(256);
+  const DTileScan scan{tile_desc, epoch};
+  if (worklist && filt_begin < filt_end && tile_desc)
     hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, filt_begin, filt_end,
-                       worklist, hits);
+                       worklist, hits, scan, tile_stride);
   else
-    hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, 0u, 0u, worklist, hits);
+    hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, 0u, 0u, worklist, hits,
+                       scan, tile_stride);
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   DeviceCounters* counters, bool count_tests, int variant)
@@ -2602,13 +2652,14 @@ void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, 
 }
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi, uint32_t filt_begin,
-                    uint32_t filt_end, uint32_t* worklist)
+                    uint32_t filt_end, uint32_t* worklist, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch)
 {
-  const dim3 grid(div_up(max_paths, 256u * kListPer), bi.count), block(256);
+  const dim3 grid(div_up(max_paths, 256u * kListPer) * bi.count), block(256);
+  const DTileScan scan{tile_desc, epoch};
 #define PT_SPHERES(FIRST, FILTER)                                                                                              \
   hipLaunchKernelGGL((k_spheres<FIRST, FILTER>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, counters, bi, \
-                     filt_begin, filt_end, worklist)
-  if (worklist && filt_begin < filt_end) {
+                     filt_begin, filt_end, worklist, scan, tile_stride)
+  if (worklist && filt_begin < filt_end && tile_desc) {
     if (first) PT_SPHERES(true, true);
     else PT_SPHERES(false, true);
   } else {

@@ -81,7 +81,7 @@ struct ptc_ctx {
     uint32_t* chunk_offsets = nullptr;
     unsigned long long* tile_desc = nullptr;  // k_shade_fused: look-back descriptors, tile_stride per frame of the batch
     uint32_t tile_stride = 0;
-    uint32_t shade_epoch = 0;           // launches of k_shade_fused on these descriptors so far (1 .. 2^30 - 1, then round again)
+    uint32_t shade_epoch = 0;           // look-back launches on these descriptors so far (1 .. 2^30 - 1, then round again)
     uint32_t* slow_list = nullptr;  // slots of rays set aside for the exact redo at the end of a traversal launch
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
@@ -1193,6 +1193,13 @@ namespace {
 // resident at five per SIMD).  Measured on single 1080p frames (2 M rays at the first bounce, 65 k at the eighth): one size
 // for all bounces 2.60 ms per frame, sized per bounce 2.1 ms.  The ray count of a bounce lives on the device; the
 // host sizes with the counts of a recent frame (FrameSlot::live_host), a bounce it knows nothing about with its cap.
+// the epoch of the next look-back launch on a slot's tile descriptors (k_shade_fused, the listing k_raygen / k_spheres)
+uint32_t next_epoch(ptc_ctx::FrameSlot& sl)
+{
+  sl.shade_epoch = sl.shade_epoch >= 0x3fffffffu ? 1u : sl.shade_epoch + 1u;
+  return sl.shade_epoch;
+}
+
 uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce)
 {
   for (auto& sl : ctx->slots)
@@ -1262,7 +1269,8 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
                     ctx->launches[0].pre_begin == ctx->launches[0].pre_end;
   const uint32_t first_mesh = sl.first_listed ? ctx->launches[0].mesh : 0u;
   launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters, ctx->scene.objects, first_mesh,
-                sl.first_listed ? first_mesh + (uint32_t)launch_run(ctx, 0) : 0u, sl.first_listed ? sl.worklist : nullptr, sl.hits);
+                sl.first_listed ? first_mesh + (uint32_t)launch_run(ctx, 0) : 0u, sl.first_listed ? sl.worklist : nullptr, sl.hits,
+                sl.tile_desc, sl.tile_stride, next_epoch(sl));
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->active_slot = f;
   return PTC_OK;
@@ -1312,7 +1320,8 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       const bool listed = by_spheres || (bounce == 0 && k == 0 && sl.first_listed);  // (bounce 0's first launch: listed by k_raygen)
       if (l.pre_begin < l.pre_end) {
         launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi,
-                       by_spheres ? l.mesh : 0u, by_spheres ? l.mesh + (uint32_t)run : 0u, by_spheres ? sl.worklist : nullptr);
+                       by_spheres ? l.mesh : 0u, by_spheres ? l.mesh + (uint32_t)run : 0u, by_spheres ? sl.worklist : nullptr,
+                       sl.tile_desc, sl.tile_stride, by_spheres ? next_epoch(sl) : 0u);
         wrote = true;
       }
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
@@ -1344,7 +1353,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   uint8_t* octs = ctx->ray_sort && !last ? sl.octs : nullptr;
   if (ctx->fused_shade) {
     // one pass: trailing spheres + material + stable compaction (decoupled look-back) + final gather
-    sl.shade_epoch = sl.shade_epoch >= 0x3fffffffu ? 1u : sl.shade_epoch + 1u;
+    next_epoch(sl);
     launch_shade_fused(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, out, sl.hits, ctx->pix_count,
                        ctx->staging(), bounce, last, slot_base_dev, sl.tile_desc, sl.tile_stride, sl.shade_epoch, sl.stage, ctx->band,
                        sl.counters, octs, sl.bi);
