@@ -249,11 +249,14 @@ void launch_instance_triangles(hipStream_t stream, const m4& m, const float* d_p
 // filt_begin < filt_end and worklist != null: the bounce's first launch is a traversal launch over the mesh objects
 // [filt_begin, filt_end); raygen lists the rays that may hit them (in slot order: a look-back scan on the descriptors
 // tile_desc -- k_shade_fused's, tile_stride per frame -- under a launch epoch of its own) and writes the miss record of
-// the others into `hits`
+// the others into `hits`.  finish_misses (that launch walks the scene's whole object list, so an unlisted ray hits
+// nothing): the unlisted rays end in raygen -- sky into fb (the shade kernels' frame: staged, or the framebuffers) -- and
+// bounce 0's launch_shade_fused gets list = worklist
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters, const DObject* objects = nullptr, uint32_t filt_begin = 0u,
                    uint32_t filt_end = 0u, uint32_t* worklist = nullptr, DHits hits = DHits{nullptr, nullptr},
-                   unsigned long long* tile_desc = nullptr, uint32_t tile_stride = 0u, uint32_t epoch = 0u);
+                   unsigned long long* tile_desc = nullptr, uint32_t tile_stride = 0u, uint32_t epoch = 0u,
+                   bool finish_misses = false, DFrame fb = DFrame{nullptr, nullptr}, bool staged = false);
 // variant 0: reference-order traversal (k_trace); 1: culled near-first traversal over the wide layout (k_trace_wide)
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   DeviceCounters* counters, bool count_tests, int variant);
@@ -296,11 +299,13 @@ void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHi
                   const DBatchInfo& bi);
 // the end of a bounce in one pass (k_shade_fused): trailing sphere run [obj_begin, obj_end) + material + stable compaction +
 // final gather.  tile_desc: shade_tiles_per_frame(max_paths) descriptors per frame of the batch (tile_stride apart), zero
-// at allocation and never cleared; epoch: a number no earlier launch on these descriptors has used (1 .. 2^30 - 1)
+// at allocation and never cleared; epoch: a number no earlier launch on these descriptors has used (1 .. 2^30 - 1).
+// list: bounce 0 after launch_raygen(finish_misses): the work list of the bounce's one traversal launch -- the kernel
+// walks it (DeviceCounters::list_count entries per frame) instead of all slots
 void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths in, DPaths out,
                         DHits hits, uint32_t max_paths, bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
                         unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb, DBand band,
-                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi);
+                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list = nullptr);
 uint32_t shade_tiles_per_frame(uint32_t max_paths);
 void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi);
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,

@@ -743,10 +743,16 @@ __device__ __forceinline__ void list_rays(uint32_t may_mask, uint32_t* worklist,
 // (no sphere run in front of it): the rays that may hit one of their world boxes go on its work list, the others get
 // their miss record here (what that launch would have written for them) -- the sky pixels of an outdoor scene never
 // reach the traversal kernel.
-template <bool kFilter>
+// kFinish (with kFilter, when that launch walks the scene's WHOLE object list): a ray that is not listed hits nothing at
+// all, so its path ends here -- throughput (1, 1, 1) times the sky into the frame, exactly what the shade kernel does
+// for a miss at bounce 0 (path_tracer.cu:304-307, ray_gen.cu:26-28) -- and neither its ray nor a miss record is written;
+// bounce 0's k_shade_fused then walks the work list instead of all slots.  Per sky pixel and frame: 32 bytes written
+// here instead of 48, and 48 bytes the shade kernel no longer reads.
+template <bool kFilter, bool kFinish>
 __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DBand band, uint32_t pix_count,
                                                 DPaths paths, DeviceCounters* counters, const DObject* objects, uint32_t filt_begin,
-                                                uint32_t filt_end, uint32_t* worklist, DHits hits, DTileScan scan, uint32_t tile_stride)
+                                                uint32_t filt_end, uint32_t* worklist, DHits hits, DTileScan scan, uint32_t tile_stride,
+                                                DFrame fb, int staged)
 {
   const uint32_t frame = blockIdx.x % bi.count;  // see DBatchInfo; frame-fastest: neighbouring workgroups take their tickets on different lines
   const DCamera& cam = cams.c[frame];
@@ -755,6 +761,11 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
   paths.d4 += (size_t)frame * bi.stride;
   counters += frame;
   scan.desc += (size_t)frame * tile_stride;
+  if (kFinish && staged) {
+    fb.color4 += (size_t)frame * bi.stride;
+    fb.nd4 += (size_t)frame * bi.stride;
+  }
+  const uint32_t acc_iteration = staged ? 0u : iteration;
   const uint32_t tiles = gridDim.x / bi.count;
   const uint32_t tile = kFilter ? list_tile(counters, tiles) : blockIdx.x / bi.count;
   const uint32_t block_first = tile * (256u * kListPer);  // a workgroup generates kListPer x 256 consecutive slots
@@ -776,15 +787,23 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
     const float fy = (float)y + rng.uniform();
     f3 o, d;
     generate_ray(cam, fx, fy, o, d);
+    bool may_hit = true;
+    if (kFilter) {
+      may_hit = may_hit_boxes(objects, filt_begin, filt_end, o, d, FLT_MAX);
+      may_mask |= may_hit ? 1u << j : 0u;
+    }
+    if (kFinish && !may_hit) {
+      const uint32_t local_pixel = band_local(band, pixel);
+      const f3 color = mk3(1.0f, 1.0f, 1.0f) * background(d);
+      accumulate_nd(fb.nd4, local_pixel, acc_iteration, -d, 1e6f);
+      accumulate_color(fb.color4, local_pixel, acc_iteration, color);
+      continue;
+    }
     stnt(&paths.o4[s], make_float4(o.x, o.y, o.z, __uint_as_float(pixel)));
     stnt(&paths.d4[s], make_float4(d.x, d.y, d.z, 0.0f));
     // (the throughput of a primary ray is (1, 1, 1), ray_gen.cu:25: the shade kernels know that at bounce 0 and neither
     // is it written here nor read there -- 32 bytes per pixel and frame less)
-    if (kFilter) {
-      const bool may_hit = may_hit_boxes(objects, filt_begin, filt_end, o, d, FLT_MAX);
-      if (!may_hit) stnt(&hits.tp[(size_t)frame * bi.stride + s], make_float4(-1.0f, 0.f, 0.f, 0.f));
-      may_mask |= may_hit ? 1u << j : 0u;
-    }
+    if (kFilter && !may_hit) stnt(&hits.tp[(size_t)frame * bi.stride + s], make_float4(-1.0f, 0.f, 0.f, 0.f));
   }
   if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, tile, tiles, scan);
 }
@@ -1095,15 +1114,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // launch on this stream starts from zero -- the redo list, the sign-off counter and the fetch cursors of this launch's
 // set for every frame of the batch (plain stores: the next launch starts after this one has completed).
 __device__ __forceinline__ void launch_epilogue(DeviceCounters* counters, int bounce, int work_slot, uint32_t redone,
-                                                const DBatchInfo& bi)
+                                                const DBatchInfo& bi, bool was_listed)
 {
   for (uint32_t i = threadIdx.x; i < bi.count * 8u; i += (uint32_t)kWave) counters[i >> 3].work[work_slot][i & 7u][0] = 0u;
-  // (a work list is used once; what was on it goes into the profile)
+  // what was on the work lists goes into the profile (list_count itself stays: the kernel that builds a list always
+  // writes it, and bounce 0's k_shade_fused may walk the same list after this launch)
   uint32_t listed = 0u;
-  for (uint32_t f = threadIdx.x; f < bi.count; f += (uint32_t)kWave) {
-    listed += counters[f].list_count;
-    counters[f].list_count = 0u;
-  }
+  if (was_listed)
+    for (uint32_t f = threadIdx.x; f < bi.count; f += (uint32_t)kWave) listed += counters[f].list_count;
   listed = wave_sum(listed);
   if (threadIdx.x == 0u) {
     counters->listed_rays[bounce] += listed;
@@ -1667,7 +1685,7 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   if (prev + 1u != gridDim.x) return;
   const uint32_t count = __hip_atomic_load(&counters->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (count != 0u) redo_slow_rays<kFirst>(sc, obj_index, paths, hits, slow_list, count, counters);
-  launch_epilogue(counters, bounce, work_slot, count, bi);
+  launch_epilogue(counters, bounce, work_slot, count, bi, listed != 0);
 }
 
 #include "pt_traverse4m.inc"
@@ -1964,7 +1982,7 @@ template <bool kSpheres, bool kFirst>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
                                                      int staged, int bounce, int last_bounce, const uint32_t* slot_base,
                                                      unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb,
-                                                     DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi)
+                                                     DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi, const uint32_t* list)
 {
   __shared__ uint32_t s_excl, s_tile;
   __shared__ uint32_t s_cnt[kFuseK * 4];
@@ -1987,7 +2005,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     fb.nd4 += fo;
   }
   counters += frame;
-  const uint32_t n = counters->live[bounce];
+  // list ("filter_rays", bounce 0 of a scene whose whole object list is the bounce's one listed traversal launch): the
+  // rays that are not on the launch's work list have been finished by k_raygen, which knew that they hit nothing; this
+  // kernel then walks the list (slot order: the survivors land where they would have) instead of all slots
+  const uint32_t n_all = counters->live[bounce];
+  const uint32_t n = list ? counters->list_count : n_all;
+  if (list) list += fo;
   const uint32_t tiles = (n + kFuseTile - 1u) / kFuseTile;
   const uint32_t wave = threadIdx.x >> 6;
   if (threadIdx.x == 0u) {
@@ -2006,12 +2029,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   // ---- phase 1: rays and hits of the tile; the closest hit is final after the trailing sphere run ----
   float4 o4[kFuseK], d4[kFuseK], tp[kFuseK], nm[kFuseK];
   uint32_t have_nm = 0u, hit_mask = 0u;
+  uint32_t slot_of[kFuseK];  // position tile * kFuseTile + j * 256 + thread of the walk -> slot (the same unless `list`)
 #pragma unroll
   for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    const uint32_t at = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    slot_of[j] = at < n ? (list ? list[at] - (uint32_t)fo : at) : n_all;
+  }
+#pragma unroll
+  for (int j = 0; j < kFuseK; ++j) {
+    const uint32_t s = slot_of[j];
     tp[j] = make_float4(-1.0f, 0.f, 0.f, 0.f);
     nm[j] = o4[j] = d4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < n) {
+    if (s < n_all) {
       o4[j] = ldnt(&in.o4[s]);
       d4[j] = ldnt(&in.d4[s]);
       if (!kFirst) tp[j] = ldnt(&hits.tp[s]);
@@ -2019,8 +2048,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
 #pragma unroll
   for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
-    if (kSpheres && s < n) {
+    const uint32_t s = slot_of[j];
+    if (kSpheres && s < n_all) {
       Ray ray;
       ray.o = xyz(o4[j]);
       ray.d = xyz(d4[j]);
@@ -2035,7 +2064,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         have_nm |= 1u << j;
       }
     }
-    const bool hit = s < n && tp[j].x >= 0.0f;
+    const bool hit = s < n_all && tp[j].x >= 0.0f;
     hit_mask |= hit ? 1u << j : 0u;
     const uint64_t live = __ballot(hit && !last_bounce);
     if ((threadIdx.x & 63u) == 0u) s_cnt[j * 4 + (int)wave] = (uint32_t)__popcll(live);
@@ -2044,9 +2073,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   float4 t4[kFuseK];
 #pragma unroll
   for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    const uint32_t s = slot_of[j];
     t4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < n) t4[j] = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ldnt(&in.t4[s]);  // (k_raygen does not write it)
+    if (s < n_all) t4[j] = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ldnt(&in.t4[s]);  // (k_raygen does not write it)
     if (!kFirst && (hit_mask >> j & 1u) && !(have_nm >> j & 1u)) nm[j] = ldnt(&hits.nm[s]);
   }
   __syncthreads();
@@ -2064,10 +2093,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   uint32_t surv_mask = 0u;
 #pragma unroll
   for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
+    const uint32_t s = slot_of[j];
     f3 ro = xyz(o4[j]), rd = xyz(d4[j]), color = xyz(t4[j]);
     uint32_t pixbits = __float_as_uint(o4[j].w);
-    if (s < n) {
+    if (s < n_all) {
       const uint32_t pixel = pixbits & 0x7fffffffu;
       const uint32_t local_pixel = band_local(band, pixel);
       bool tmin_flag = (pixbits >> 31) != 0u;
@@ -2112,8 +2141,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       s_excl = excl;
       if (tile + 1u == tiles) {  // the last tile knows the frame's total (k_scan's epilogue)
         counters->live[bounce + 1] = last_bounce ? 0u : excl + agg;
-        counters->rays_total += n;
-        counters->paths[bounce] += n;
+        counters->rays_total += n_all;
+        counters->paths[bounce] += n_all;
       }
     }
   }
@@ -2627,16 +2656,22 @@ static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b;
 
 void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count,
                    DPaths paths, DeviceCounters* counters, const DObject* objects, uint32_t filt_begin, uint32_t filt_end,
-                   uint32_t* worklist, DHits hits, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch)
+                   uint32_t* worklist, DHits hits, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch,
+                   bool finish_misses, DFrame fb, bool staged)
 {
   const dim3 grid(div_up(pix_count, 256u * kListPer) * bi.count), block(256);
   const DTileScan scan{tile_desc, epoch};
-  if (worklist && filt_begin < filt_end && tile_desc)
-    hipLaunchKernelGGL(k_raygen<true>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, filt_begin, filt_end,
-                       worklist, hits, scan, tile_stride);
-  else
-    hipLaunchKernelGGL(k_raygen<false>, grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, 0u, 0u, worklist, hits,
-                       scan, tile_stride);
+  if (worklist && filt_begin < filt_end && tile_desc) {
+    if (finish_misses)
+      hipLaunchKernelGGL((k_raygen<true, true>), grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, filt_begin,
+                         filt_end, worklist, hits, scan, tile_stride, fb, staged ? 1 : 0);
+    else
+      hipLaunchKernelGGL((k_raygen<true, false>), grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, filt_begin,
+                         filt_end, worklist, hits, scan, tile_stride, fb, 0);
+  } else {
+    hipLaunchKernelGGL((k_raygen<false, false>), grid, block, 0, s, cams, bi, band, pix_count, paths, counters, objects, 0u, 0u, worklist,
+                       hits, scan, tile_stride, fb, 0);
+  }
 }
 void launch_trace(hipStream_t s, const DScene& scene, DPaths paths, DHits hits, uint32_t max_paths, int bounce,
                   DeviceCounters* counters, bool count_tests, int variant)
@@ -2724,12 +2759,12 @@ void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHi
 void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths in, DPaths out,
                         DHits hits, uint32_t max_paths, bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
                         unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb, DBand band,
-                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi)
+                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list)
 {
   const dim3 grid(div_up(max_paths, kFuseTile) * bi.count), block(256);
 #define PT_FUSED(SPH, FIRST)                                                                                                   \
   hipLaunchKernelGGL((k_shade_fused<SPH, FIRST>), grid, block, 0, s, scene, obj_begin, obj_end, in, out, hits, staged ? 1 : 0, \
-                     bounce, last_bounce ? 1 : 0, slot_base, tile_desc, tile_stride, epoch, fb, band, counters, octs, bi)
+                     bounce, last_bounce ? 1 : 0, slot_base, tile_desc, tile_stride, epoch, fb, band, counters, octs, bi, list)
   if (obj_begin < obj_end) {
     if (first) PT_FUSED(true, true);
     else PT_FUSED(true, false);

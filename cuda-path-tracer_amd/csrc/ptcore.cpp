@@ -86,6 +86,7 @@ struct ptc_ctx {
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
     uint32_t* order = nullptr;      // ... and the order in which the traversal lanes pick them up
+    bool primary_finished = false;  // ... and finished the others itself: bounce 0's shade walks the list (launch_raygen)
     bool first_listed = false;      // ... k_raygen has listed the rays of bounce 0's first traversal launch (this batch)
     uint32_t* worklist = nullptr;   // "filter_rays": the rays of the next traversal launch that may hit one of its objects (k_spheres)
     uint2* spill = nullptr;         // traversal stack overflow area of this slot's launches (DScene::spill)
@@ -1268,9 +1269,18 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   sl.first_listed = ctx->filter_rays && ctx->trace_variant == 3 && !ctx->launches.empty() &&
                     ctx->launches[0].pre_begin == ctx->launches[0].pre_end;
   const uint32_t first_mesh = sl.first_listed ? ctx->launches[0].mesh : 0u;
-  launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters, ctx->scene.objects, first_mesh,
-                sl.first_listed ? first_mesh + (uint32_t)launch_run(ctx, 0) : 0u, sl.first_listed ? sl.worklist : nullptr, sl.hits,
-                sl.tile_desc, sl.tile_stride, next_epoch(sl));
+  uint32_t filt_end = sl.first_listed ? first_mesh + (uint32_t)launch_run(ctx, 0) : 0u;
+  // ... and when that launch is the scene's whole mesh part -- only the sphere run that ends the object list, if any,
+  // follows it -- the filter also takes the world boxes of those spheres (the reference tests a sphere's box before the
+  // sphere, path_tracer.cu:84): a ray it does not list then hits nothing at all, raygen ends its path, and bounce 0's
+  // k_shade_fused walks the list.  (The few rays listed for a sphere's box alone leave the traversal launch at its root.)
+  const bool tail = ctx->tail_begin < ctx->tail_end;
+  sl.primary_finished = sl.first_listed && ctx->fused_shade && launch_run(ctx, 0) == ctx->launches.size() &&
+                        (!tail || ctx->tail_begin == filt_end);
+  if (sl.primary_finished && tail) filt_end = ctx->tail_end;
+  launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters, ctx->scene.objects, first_mesh, filt_end,
+                sl.first_listed ? sl.worklist : nullptr, sl.hits, sl.tile_desc, sl.tile_stride, next_epoch(sl), sl.primary_finished,
+                sl.stage, ctx->staging());
   if (int rc = check_last(ctx, "raygen")) return rc;
   ctx->active_slot = f;
   return PTC_OK;
@@ -1356,7 +1366,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     next_epoch(sl);
     launch_shade_fused(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, out, sl.hits, ctx->pix_count,
                        ctx->staging(), bounce, last, slot_base_dev, sl.tile_desc, sl.tile_stride, sl.shade_epoch, sl.stage, ctx->band,
-                       sl.counters, octs, sl.bi);
+                       sl.counters, octs, sl.bi, bounce == 0 && sl.primary_finished ? sl.worklist : nullptr);
   } else {
     launch_tail_count(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, sl.hits, ctx->pix_count,
                       bounce, sl.chunk_counts, sl.counters, sl.bi);

@@ -33,8 +33,29 @@ def tail(path, spec):
         print(f"# last {len(d)} dispatches of *{sub}*: avg {sum(d) / len(d) / 1e3:.2f} us, min {min(d) / 1e3:.2f}, max {max(d) / 1e3:.2f}")
 
 
+def timeline(path, n):
+    """--timeline N  the last N dispatches of this library's kernels in start order: start (us after the first of them), duration, gap to the end of
+    the latest dispatch before it (what a stream loses between dependent kernels)"""
+    c = sqlite3.connect(path)
+    rows = c.execute("select name, start, end, grid_x, workgroup_x from kernels where name like '%pt::%' order by start desc limit ?", (int(n),)).fetchall()[::-1]
+    if not rows:
+        return
+    t0, last_end, busy, gaps = rows[0][1], None, 0, 0
+    print(f"# last {len(rows)} dispatches")
+    for name, st, en, gx, wx in rows:
+        short = name.replace("void ", "").split("(")[0][-40:]
+        gap = (st - last_end) / 1e3 if last_end is not None else 0.0
+        print(f"{short:<40} start {(st - t0) / 1e3:>10.1f}  dur {(en - st) / 1e3:>9.1f}  gap {gap:>8.1f}  grid {gx // max(wx, 1)}")
+        busy += en - st
+        gaps += max(gap, 0.0)
+        last_end = en if last_end is None else max(last_end, en)
+    print(f"# span {(last_end - t0) / 1e3:.1f} us, kernels {busy / 1e3:.1f} us, gaps {gaps:.1f} us")
+
+
 if __name__ == "__main__":
     main(sys.argv[1], by_grid="--by-grid" in sys.argv[2:])
     for i, a in enumerate(sys.argv):
         if a == "--tail":
             tail(sys.argv[1], sys.argv[i + 1])
+        if a == "--timeline":
+            timeline(sys.argv[1], sys.argv[i + 1])
