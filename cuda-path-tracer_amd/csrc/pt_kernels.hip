@@ -2022,7 +2022,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   __syncthreads();
   const uint32_t tile = s_tile;
   if (tile >= tiles) {
-    if (tiles == 0u && tile == 0u && threadIdx.x == 0u) counters->live[bounce + 1] = 0u;  // nothing alive: nothing follows
+    if (tiles == 0u && tile == 0u && threadIdx.x == 0u) {  // nothing alive: nothing follows
+      counters->live[bounce + 1] = 0u;
+      counters->rays_total += n_all;  // (not zero when k_raygen has finished every ray of the frame, see `list`)
+      counters->paths[bounce] += n_all;
+    }
     return;
   }
 
