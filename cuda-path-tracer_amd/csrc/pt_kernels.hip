@@ -677,14 +677,15 @@ struct DTileScan {
 __device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc, uint32_t tile, uint32_t epoch, uint32_t* flags);
 constexpr unsigned long long kDescAggregate = 1ull << 32, kDescPrefix = 2ull << 32;
 
-// the tile of this workgroup: tickets of the frame's counter, handed out in the order the workgroups start
-__device__ __forceinline__ uint32_t list_tile(DeviceCounters* counters, uint32_t workgroups_per_frame)
+// the tile of this workgroup: tickets of the frame's counter, handed out in the order the workgroups start.  Exactly
+// `tiles` workgroups of the frame call this (the others have left, see k_shade_fused).
+__device__ __forceinline__ uint32_t list_tile(DeviceCounters* counters, uint32_t tiles)
 {
   __shared__ uint32_t s_list_tile;
   if (threadIdx.x == 0u) {
     const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every workgroup of the frame has its ticket once the last one is out: the next launch starts from zero
-    if (t + 1u == workgroups_per_frame) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every tile of the frame is taken once the last ticket is out: the next launch starts from zero
+    if (t + 1u == tiles) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_list_tile = t;
   }
   __syncthreads();
@@ -1714,12 +1715,12 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   scan.desc += (size_t)frame * tile_stride;
   const uint32_t n = counters->live[bounce];
   const uint32_t tiles = (n + 256u * kListPer - 1u) / (256u * kListPer);
-  const uint32_t tile = kFilter ? list_tile(counters, gridDim.x / bi.count) : blockIdx.x / bi.count;
-  const uint32_t block_first = tile * (256u * kListPer);  // a workgroup tests kListPer x 256 consecutive slots
-  if (tile >= tiles) {
-    if (kFilter && tiles == 0u && tile == 0u && threadIdx.x == 0u) counters->list_count = 0u;  // nothing alive: an empty list
+  if (blockIdx.x / bi.count >= tiles) {
+    if (kFilter && tiles == 0u && blockIdx.x / bi.count == 0u && threadIdx.x == 0u) counters->list_count = 0u;  // nothing alive: an empty list
     return;
   }
+  const uint32_t tile = kFilter ? list_tile(counters, tiles) : blockIdx.x / bi.count;
+  const uint32_t block_first = tile * (256u * kListPer);  // a workgroup tests kListPer x 256 consecutive slots
   uint32_t may_mask = 0u;
 #pragma unroll 1
   for (int j = 0; j < kListPer; ++j) {
@@ -2013,22 +2014,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   if (list) list += fo;
   const uint32_t tiles = (n + kFuseTile - 1u) / kFuseTile;
   const uint32_t wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0u) {
-    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every workgroup of the frame has its ticket once the last one is out: the next launch starts from zero
-    if (t + 1u == gridDim.x / bi.count) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_tile = t;
-  }
-  __syncthreads();
-  const uint32_t tile = s_tile;
-  if (tile >= tiles) {
-    if (tiles == 0u && tile == 0u && threadIdx.x == 0u) {  // nothing alive: nothing follows
+  // The grid is sized for a frame of all-live slots; the workgroups the frame has no tile for leave without a ticket:
+  // exactly `tiles` tickets are taken per frame.  (Dispatching the empty workgroups costs little: a launch sized by the
+  // last batch's live counts, whose workgroups came back for more tiles when there were too few, was slower -- the
+  // loop cost 24 spilled registers -- profiles/r03_shade_breakdown.txt.)
+  if (blockIdx.x / bi.count >= tiles) {
+    if (tiles == 0u && blockIdx.x / bi.count == 0u && threadIdx.x == 0u) {  // nothing alive: nothing follows
       counters->live[bounce + 1] = 0u;
       counters->rays_total += n_all;  // (not zero when k_raygen has finished every ray of the frame, see `list`)
       counters->paths[bounce] += n_all;
     }
     return;
   }
+  if (threadIdx.x == 0u) {
+    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every tile of the frame is taken once the last ticket is out: the next launch starts from zero
+    if (t + 1u == tiles) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
 
   // ---- phase 1: rays and hits of the tile; the closest hit is final after the trailing sphere run ----
   float4 o4[kFuseK], d4[kFuseK], tp[kFuseK], nm[kFuseK];
