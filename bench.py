@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight; 0 = 2 per rank on one or two GPUs, 4 per rank on more")
     ap.add_argument("--traverse-waves", type=int, default=0, help="persistent wavefronts of a full-size traversal launch (0 = tuned default)")
     ap.add_argument("--ray-sort", type=int, default=0, help="1: direction-octant ray sorting of the pick-up order (config.ray_sort)")
-    ap.add_argument("--trace-variant", type=int, default=-1, help="closest-hit kernel (-1 = the library's default; 3 four-wide, 5 eight-wide tree)")
+    ap.add_argument("--trace-variant", type=int, default=-1, help="closest-hit kernel (-1 = the library's default; 0 reference order, 1 culled two-wide, 3 persistent four-wide)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="extra ptc_set_param before the scene upload (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the steady-state and latency measurements")
