@@ -236,8 +236,11 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      ONE kernel (tiles by ticket, decoupled look-back; a bounded wait reports PTC_ERR_HIP from ptc_get_stats
  *                      instead of ever hanging); 0: three kernels (count, scan, shade)
  *   "filter_rays"      1 (default): the kernel in front of a mesh launch (a sphere run; ray generation at bounce 0) also lists the
- *                      rays that may hit one of the launch's world boxes at all, and the launch walks only those
- *                      (ptc_profile::listed_rays); 0: every live ray is fetched by the launch
+ *                      rays that may hit one of the launch's world boxes at all -- in slot order, by the look-back scan of
+ *                      "fused_shade" -- and the launch walks only those (ptc_profile::listed_rays).  When bounce 0's launch
+ *                      covers the scene's whole mesh part (only the sphere run that ends the object list follows), a primary ray
+ *                      that is not listed hits nothing: its path ends in ray generation and the bounce's shade kernel walks the
+ *                      list.  Images, live counts and ray totals are those of 0: every live ray is fetched by the launch
  *   "traverse_waves"   most persistent wavefronts a traversal launch may use (default 5120 = the number that is
  *                      resident at 5 per SIMD; before ptc_upload_scene).  A launch uses one wavefront per 3072
  *                      primary rays it carries, at least 1024
