@@ -178,6 +178,9 @@ struct ptc_ctx {
   uint64_t layout_counts[5] = {0, 0, 0, 0, 0};  // bytes of bvh4q, leaf_parent, tris, wide, bvh (ptc_download_layout)
   uint32_t split_idle = 8;    // "split_idle"
   uint32_t min_waves = 1024;  // "min_waves": fewest persistent wavefronts of a traversal launch
+  uint32_t small_waves = 3072;        // "small_waves": ... of a launch with fewer than small_rays_per_lane rays per lane of a full one
+  uint32_t small_rays_per_lane = 4;   // "small_rays_per_lane" (8 until round 3: bounces 5 and 6 of a 20-frame batch -- 5 to 8 rays
+                                      // per lane -- are 12-14 % faster on all 5120 wavefronts than on 3072)
   // live paths entering each bounce of one recent frame (what a frame of this scene / camera looks like): the host
   // never waits for them, they only size the traversal launches
   uint32_t est_live[kMaxBounces + 1] = {};
@@ -1125,6 +1128,16 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->scene.static_eighths = ctx->static_eighths;
     return PTC_OK;
   }
+  if (std::strcmp(name, "small_waves") == 0) {
+    if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "small_waves out of range");
+    ctx->small_waves = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "small_rays_per_lane") == 0) {
+    if (value < 0 || value > 1024) return fail(ctx, PTC_ERR_INVALID, "small_rays_per_lane out of range");
+    ctx->small_rays_per_lane = (uint32_t)value;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "min_waves") == 0) {
     if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "min_waves out of range");
     ctx->min_waves = (uint32_t)value;
@@ -1213,8 +1226,9 @@ uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce)
   uint64_t per_frame = ctx->pix_count;
   if (ctx->est_valid && ctx->est_live[0] == ctx->pix_count) per_frame = std::min<uint64_t>(ctx->pix_count, ctx->est_live[bounce]);
   const uint64_t rays = per_frame * frames;
-  // (fewer than eight rays per lane at full size: 3072 wavefronts do as well or a little better -- single frames)
-  const uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * 8u ? ctx->traverse_waves : std::min<uint32_t>(ctx->traverse_waves, 3072u);
+  // (fewer than four rays per lane at full size: 3072 wavefronts do as well or a little better -- single frames)
+  const uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * ctx->small_rays_per_lane ? ctx->traverse_waves
+                                                                                                 : std::min<uint32_t>(ctx->traverse_waves, ctx->small_waves);
   const uint64_t want = ((rays + kWave - 1u) / kWave + 7u) & ~7ull;
   return (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(std::min<uint32_t>(ctx->min_waves, ctx->traverse_waves), want));
 }

@@ -263,6 +263,8 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      with a copy of its ray; default 8, 0 = never).  Cuts the latency tail of every launch
  *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 3 = 3/8)
+ *   "small_waves", "small_rays_per_lane"  a traversal launch with fewer than small_rays_per_lane (default 4) rays per lane of
+ *                      "traverse_waves" wavefronts uses at most small_waves (default 3072) of them
  *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small
  *                      scenes exercise the global overflow area (1..24; before ptc_upload_scene)
  *   "debug_force_slow" test hook: route every ray through the exact redo at the end of the traversal launch */
