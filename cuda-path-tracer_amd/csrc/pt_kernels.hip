@@ -1031,6 +1031,7 @@ struct BatchFeed {
     in_static = static_eighths != 0u;
     done = false;
     // dynamic batches: one atomic hands out this many rays (a cursor line sustains ~30 atomics/us)
+    // (re-measured on round 3's final build: 64 everywhere -6 %, 256 or other thresholds within noise)
     dyn_batch = (uint64_t)n * count / gridDim.x >= 256u ? 128u : (uint32_t)kWave;
   }
   __device__ __forceinline__ bool exhausted() const { return !in_static && done; }
