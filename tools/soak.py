@@ -12,7 +12,9 @@ ref = None
 for name, params, variant in (("defaults", (), None),
                               ("8 x 1-frame launches, 1024 wavefronts", (("frames_in_flight", 8), ("batch_frames", 1), ("traverse_waves", 1024)), None),
                               ("4 x 8-frame launches, 2048 wavefronts, static 7/8", (("frames_in_flight", 32), ("batch_frames", 8), ("traverse_waves", 2048), ("static_eighths", 7)), None),
-                              ("12 x 1-frame launches, 6 stack entries in LDS", (("frames_in_flight", 12), ("batch_frames", 1), ("debug_lds_entries", 6)), None)):
+                              ("12 x 1-frame launches, 6 stack entries in LDS", (("frames_in_flight", 12), ("batch_frames", 1), ("debug_lds_entries", 6)), None),
+                              ("no ray filter, three-kernel end of a bounce, 3 x 20-frame launches", (("filter_rays", 0), ("fused_shade", 0), ("frames_in_flight", 60), ("batch_frames", 20)), None),
+                              ("ray filter without the fused shade kernel, 5 x 7-frame launches", (("fused_shade", 0), ("frames_in_flight", 35), ("batch_frames", 7)), None)):
     with pkg.PathTracer(max_bounces=8) as pt:
         for k, v in params: pt.set_param(k, v)
         pt.create_buffers((W, H), flat); pt.max_iterations = 1 << 30
