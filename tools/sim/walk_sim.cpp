@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -109,7 +110,13 @@ static bool tri_hit(const Ray& r, uint32_t t, float tmax, float& tout)
   return true;
 }
 
-struct Stats { double nodes = 0, boxes = 0, tris = 0, iters = 0; uint32_t max_nodes = 0; };
+struct Stats { double nodes = 0, boxes = 0, tris = 0, iters = 0, blocks = 0, valu = 0; uint32_t max_nodes = 0; };
+// leaf blocks (model of an idea): a wide node all of whose children are single-triangle leaves is
+// walked as ONE iteration that tests all its triangles unconditionally, instead of one node iteration plus one
+// iteration per child whose box the ray passes.  valu: modelled VALU instructions (node step 140, triangle test 60,
+// 30 per iteration for the loop, the fetch and the stack).
+static bool g_leaf_blocks = false;
+static int g_block_per_iter = 4;  // triangles of a block one iteration can test (register budget of the loads)
 
 // order: 0 = children sorted by entry distance; 1 = by the ray's direction octant (centroid projected on sign(d));
 //        2 = nearest child first, the rest in slot order; 3 = as stored
@@ -125,12 +132,29 @@ static void walk(const Ray& r, int order, Stats& st)
     const uint32_t x = stack[--sp];
     ++st.iters;
     if (nodes[x].count != 0) {
+      st.valu += 30 + 60;
       ++st.tris;
       float t;
       if (tri_hit(r, nodes[x].first / 3, best_t, t)) best_t = t;
       continue;
     }
     const WNode& w = wnodes[wide_of[x]];
+    if (g_leaf_blocks) {
+      bool all_leaves = true;
+      for (int c = 0; c < w.nk; ++c) all_leaves = all_leaves && nodes[w.kid[c]].count != 0;
+      if (all_leaves) {
+        ++st.blocks;
+        st.valu += 30 * ((w.nk + g_block_per_iter - 1) / g_block_per_iter) + 60 * w.nk;
+        st.iters += (w.nk + g_block_per_iter - 1) / g_block_per_iter - 1;
+        for (int c = 0; c < w.nk; ++c) {
+          ++st.tris;
+          float t;
+          if (tri_hit(r, nodes[w.kid[c]].first / 3, best_t, t)) best_t = t;
+        }
+        continue;
+      }
+    }
+    st.valu += 30 + 140;
     ++st.nodes;
     ++my_nodes;
     float key[8];
@@ -185,19 +209,33 @@ int main(int argc, char** argv)
   if (fread(per_bounce, 4, 8, f) != 8) return 1;
   fclose(f);
   const char* names[4] = {"sorted by entry distance", "octant order (centroids)", "nearest first, rest unsorted", "as stored (no order)"};
+  const bool blocks_only = argc > 2 && !strcmp(argv[2], "blocks");
+  if (argc > 3) g_block_per_iter = atoi(argv[3]);
   for (int k : {2, 4, 8}) {
+    if (blocks_only && k != 4) continue;
     collapse(k);
-    for (int order = 0; order < 4; ++order) {
+    for (int order = 0; order < (blocks_only ? 2 : 4); ++order) {
+      g_leaf_blocks = blocks_only && order == 1;
+      if (blocks_only) {
+        size_t nb = 0;
+        for (const WNode& w : wnodes) {
+          bool al = true;
+          for (int c = 0; c < w.nk; ++c) al = al && nodes[w.kid[c]].count != 0;
+          nb += al;
+        }
+        printf("k=4 sorted by entry distance, leaf blocks %s: %zu of %zu wide nodes have only leaves\n", g_leaf_blocks ? "ON" : "off", nb, wnodes.size());
+      }
+      const int order_used = blocks_only ? 0 : order;
       size_t at = 0;
       Stats all;
-      printf("k=%d  %-30s  wide nodes %zu\n", k, names[order], wnodes.size());
+      if (!blocks_only) printf("k=%d  %-30s  wide nodes %zu\n", k, names[order], wnodes.size());
       for (int b = 0; b < 8 && per_bounce[b]; ++b) {
         Stats st;
-        for (uint32_t i = 0; i < per_bounce[b]; ++i) walk(rays[at + i], order, st);
+        for (uint32_t i = 0; i < per_bounce[b]; ++i) walk(rays[at + i], order_used, st);
         at += per_bounce[b];
         const double n = per_bounce[b];
-        printf("   bounce %d: nodes/ray %6.2f  boxes/ray %6.2f  tris/ray %5.2f  iterations/ray %6.2f  longest %u nodes\n", b,
-               st.nodes / n, st.boxes / n, st.tris / n, st.iters / n, st.max_nodes);
+        printf("   bounce %d: nodes/ray %6.2f  boxes/ray %6.2f  tris/ray %5.2f  iterations/ray %6.2f  blocks/ray %5.2f  valu/ray %7.1f  longest %u nodes\n", b,
+               st.nodes / n, st.boxes / n, st.tris / n, st.iters / n, st.blocks / n, st.valu / n, st.max_nodes);
         all.nodes += st.nodes; all.boxes += st.boxes; all.tris += st.tris; all.iters += st.iters;
       }
       const double n = (double)at;
