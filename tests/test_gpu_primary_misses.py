@@ -79,3 +79,19 @@ def test_frame_that_is_all_sky(pkg, orc):
             assert np.array_equal(got[k], ref[k]), (k, params)
         assert got["stats"]["rays_total"] == ref["rays"]
         assert got["profile"]["listed_rays"][0] == 0
+
+
+@pytest.mark.parametrize("size", [(33, 17), (130, 70), (64, 16), (257, 4), (1030, 3)])
+def test_odd_frame_sizes_through_the_lists(pkg, orc, size):
+    """Frames that are not a whole number of 1024-slot tiles, of 64-slot wavefronts, or smaller than one tile: the
+    look-back scan of the work list, the ticketed tiles of the shade kernel and the feed's regions at their edges."""
+    w, h = size
+    iters, mb = 3, 5
+    scene = _terrain(pkg, True)
+    flat = scene.build_scene()
+    ref = orc.render_streaming(flat, scene.camera, w, h, 0, iters, mb)
+    for params in ((("frames_in_flight", 1),), (("frames_in_flight", 6), ("batch_frames", 3)), (("frames_in_flight", 2),)):
+        got = _run(pkg, scene, flat, w, h, iters, mb, params)
+        for k in ("color", "normal", "depth"):
+            assert np.array_equal(got[k], ref[k]), (k, size, params)
+        assert got["stats"]["rays_total"] == ref["rays"]
