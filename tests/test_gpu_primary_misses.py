@@ -95,3 +95,22 @@ def test_odd_frame_sizes_through_the_lists(pkg, orc, size):
         for k in ("color", "normal", "depth"):
             assert np.array_equal(got[k], ref[k]), (k, size, params)
         assert got["stats"]["rays_total"] == ref["rays"]
+
+
+@pytest.mark.parametrize("size", [(37, 29), (129, 65)])
+def test_odd_frame_sizes_with_a_sphere_run_in_front(pkg, orc, size):
+    """The other list builder: k_spheres (a Cornell box of wall spheres in front of two mesh instances, a glass sphere
+    behind them) at sizes that leave ragged tiles at every bounce."""
+    w, h = size
+    iters, mb = 3, 6
+    scene = pkg.scenes.cornell_bunny((w, h), n_lat=12, n_lon=24)
+    flat = scene.build_scene()
+    ref = orc.render_streaming(flat, scene.camera, w, h, 0, iters, mb)
+    off = _run(pkg, scene, flat, w, h, iters, mb, (("filter_rays", 0), ("frames_in_flight", 1)))
+    for params in ((("frames_in_flight", 1),), (("frames_in_flight", 6), ("batch_frames", 3)), (("frames_in_flight", 4), ("fused_shade", 0))):
+        got = _run(pkg, scene, flat, w, h, iters, mb, params)
+        for k in ("color", "normal", "depth"):
+            assert np.array_equal(got[k], ref[k]), (k, size, params)
+            assert np.array_equal(got[k], off[k]), (k, size, params)
+        assert got["stats"]["rays_total"] == ref["rays"]
+        assert sum(got["profile"]["listed_rays"]) > 0
