@@ -186,7 +186,7 @@ struct DeviceCounters {
   uint32_t slow_count;             // rays set aside for the exact redo by the running traversal launch
   uint32_t waves_done;             // wavefronts of the running traversal launch that have signed off
   uint32_t shade_ticket;           // k_shade_fused: next tile of this frame to be taken (zero between launches)
-  uint32_t list_count;             // rays k_spheres<.., kFilter> has put on the next traversal launch's work list (that launch zeroes it)
+  uint32_t list_count;             // rays k_raygen / k_spheres<.., kFilter> have put on the next traversal launch's work list (written by the list's last tile)
   unsigned long long rays_total;
   unsigned long long paths[kMaxBounces];      // sum of live[b] over frames since the last profile reset
   unsigned long long box_tests[kMaxBounces];  // instrumented runs only
