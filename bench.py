@@ -38,8 +38,13 @@ Prints ONE JSON line on rank 0 with the contract fields plus:
                 HBM-bound -- its working set lives in L2 / Infinity Cache -- so `valu` carries the roofline that
                 does bind it: VALU issue (busy %, lanes per instruction, instructions per ray; SQ counter passes,
                 profiles/pmc_sq_<frames per launch>.json).
-  parity        GPU iteration 0 of the benchmark scene against the CPU oracle's frame (the one rendered for
-                cpu_baseline): mse, bit_exact, live counts and ray count equal.
+  parity        the tracer that was just timed, restarted, against the CPU oracle's frames (the ones rendered for
+                cpu_baseline): mse, bit_exact, live counts and ray count equal.  N > 1 (and --share-of N): EVERY rank's
+                rows against the oracle's rendering of that rank (orc_render_streaming_interleaved: interleaved blocks,
+                per-rank numbering, slot_offset = rank * W * H), rank 0's first (timed: cpu_baseline), the others' after it.
+  rccl_ranks    N > 1: the sum of a device all-reduce of ones over the process group whose backend reports "nccl"
+                (asserted == N; 0 in a gloo rehearsal); distinct_devices = distinct PCI identities among the ranks' GPUs
+                (asserted == N outside a rehearsal).
   steady_state  the same workload with 32 frames per launch and 256 steps (the tuned schedule; the timed region
                 above runs exactly --steps frames, which the driver sets to 20).
   latency       ms per frame when frames are strictly serial (one frame in flight) and in the viewer pattern
@@ -260,6 +265,28 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         pt.max_iterations = 1 << 30
         return pt
 
+    # N > 1: who is really there.  rccl_ranks = what a device all-reduce of ones over the process group sums to, counted only
+    # when the group's backend for CUDA tensors is nccl (= RCCL); distinct_devices = distinct PCI identities of the ranks' GPUs.
+    rccl_ranks = distinct_devices = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = tuple(str(getattr(props, k)) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(props, k)) or None
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        distinct_devices = len(set(idents)) if all(i is not None for i in idents) else None
+        if rehearse:
+            rccl_ranks = 0
+        else:
+            ones = torch.ones(1, dtype=torch.int32, device="cuda")
+            dist.all_reduce(ones)
+            torch.cuda.synchronize()
+            rccl_ranks = int(ones.item()) if "nccl" in str(dist.get_backend()) else 0
+            if rccl_ranks != world:
+                raise SystemExit(f"bench.py: --gpus {world}, but the RCCL all-reduce over the process group sums to {rccl_ranks} "
+                                 f"(backend {dist.get_backend()})")
+            if distinct_devices is not None and distinct_devices != world:
+                raise SystemExit(f"bench.py: --gpus {world}, but the ranks sit on {distinct_devices} distinct device(s): {idents}")
+
     pt = make_tracer(batch, streams)
     # gather needs equal sizes on every rank: pad each rank's rows to the largest share
     max_rows = max(len(rr) for rr in rank_rows)
@@ -412,7 +439,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     timed_frames = None
     cw, ch = (int(v) for v in args.cpu_sample.split("x")) if args.cpu_sample else (W, H)
     cpu_frames = max(1, min(args.cpu_frames, args.steps))
-    if rank == 0 and split == 1 and not args.no_cpu_baseline and (cw, ch) == (W, H):
+    if (rank == 0 or split > 1) and not args.no_cpu_baseline and (cw, ch) == (W, H):
         pt.restart()
         r0 = pt.stats()["rays_total"]
         for _ in range(cpu_frames):
@@ -426,6 +453,11 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=pmc_scene,
                               pixels=W * H // split, frames=args.steps)
     slow_rays = sum(prof["slow_rays"])
+    walked_total = roofline["rays_walked_by_the_launches"]
+    if world > 1:   # every rank's traversal launches
+        wt = torch.tensor([walked_total], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(wt, op=dist.ReduceOp.SUM)
+        walked_total = int(wt.item())
 
     # the tuned schedule on the same workload (only when the timed region above was too short to show it)
     steady = None
@@ -442,7 +474,8 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                   "roofline_frac": s_roof["frac"], "roofline_achieved": s_roof["achieved"],
                   "avg_launch_us": s_roof["avg_launch_us"], "traffic": s_roof["traffic"],
                   "frac_requested": s_roof["frac_requested"], "concurrent_launches": s_roof["concurrent_launches"],
-                  "frame_level_frac": (s_roof.get("frame_level") or {}).get("frac"), "per_bounce": s_roof["per_bounce"]}
+                  "frame_level_frac": (s_roof.get("frame_level") or {}).get("frac"), "per_bounce": s_roof["per_bounce"],
+                  "mrays_per_s_walked_rank0": round(s_roof["rays_walked_by_the_launches"] / s_el / 1e6, 3)}
     pt.close()
 
     # single-frame latency: strictly serial frames, and the viewer pattern (app.cpp:141-170 presents every frame)
@@ -473,6 +506,14 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             lp.close()
 
     cpu_baseline = parity = None
+
+    def compare(got, ref):
+        d = got["color"].astype(np.float64) - ref["color"].astype(np.float64)
+        return {"mse": float(np.mean(np.sum(d * d, axis=-1))),
+                "bit_exact": bool(all(np.array_equal(got[k], ref[k]) for k in ("color", "normal", "depth"))),
+                "live_equal": bool(got["last_live"][:MB] == [int(v) for v in ref["live"][-1][:MB]]),
+                "rays_equal": bool(got["rays"] == ref["rays"])}
+
     if rank == 0 and split == 1 and not args.no_cpu_baseline:
         orc = graft.load_oracle()
         sh = orc.SceneHandle(flat)
@@ -496,19 +537,59 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                 st = cp.stats()
                 got["rays"], got["last_live"] = st["rays_total"], st["last_live"]
             what = "a tracer of the sample's size, default schedule"
-        d = got["color"].astype(np.float64) - ref["color"].astype(np.float64)
         parity = {"against": "the CPU oracle's %d accumulated iterations at %dx%d (the frames of cpu_baseline)" % (cpu_frames, cw, ch),
-                  "gpu_side": what,
-                  "mse": float(np.mean(np.sum(d * d, axis=-1))),
-                  "bit_exact": bool(all(np.array_equal(got[k], ref[k]) for k in ("color", "normal", "depth"))),
-                  "live_equal": bool(got["last_live"][:MB] == [int(v) for v in ref["live"][-1][:MB]]),
-                  "rays_equal": bool(got["rays"] == ref["rays"]), "tolerance_mse": 1e-4}
+                  "gpu_side": what, **compare(got, ref), "tolerance_mse": 1e-4}
+    elif split > 1 and not args.no_cpu_baseline and timed_frames is not None:
+        # The split that was timed (interleaved row blocks, per-rank numbering, slot_offset = rank * W * H) against the oracle's
+        # rendering of the same rank's rows.  Rank 0 goes first and alone -- its oracle run is the cpu_baseline sample -- then
+        # the other ranks check their own rows side by side on what is left of the host's cores.
+        orc = graft.load_oracle()
+        sh = orc.SceneHandle(flat)
+        hw = orc.lib().orc_hardware_threads()
+        cores = max(1, min(args.cpu_threads, hw))
+        mine = None
+        if rank == 0:
+            t0 = time.perf_counter()
+            ref = orc.render_interleaved(flat, scene.camera, W, H, 0, split, BLOCK_ROWS, 0, 0, cpu_frames, MB, nthreads=cores, scene_handle=sh)
+            dt = time.perf_counter() - t0
+            cpu_baseline = {"value": round(ref["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                            "sample": f"rank 0's rows of the {split}-way split ({len(rank_rows[0])} of {H} rows in blocks of {BLOCK_ROWS}), "
+                                      f"{cpu_frames} accumulated iterations, same {len(flat.indices) // 3}-triangle BVH, {MB} bounces: "
+                                      f"{ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so (CPU restatement; the reference has no CPU path)"}
+            mine = {"rank": 0, **compare(timed_frames, ref)}
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            share = max(1, min(args.cpu_threads, hw // max(world - 1, 1)))
+            ref = orc.render_interleaved(flat, scene.camera, W, H, rank, split, BLOCK_ROWS, rank * W * H, 0, cpu_frames, MB,
+                                         nthreads=share, scene_handle=sh)
+            mine = {"rank": rank, **compare(timed_frames, ref)}
+        every = [mine]
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        if rank == 0:
+            parity = {"against": "the CPU oracle's rendering of each rank's rows (orc_render_streaming_interleaved: blocks of %d rows dealt over %d "
+                                 "ranks, paths numbered per rank, slot_offset = rank * W * H), %d accumulated iterations at %dx%d"
+                                 % (BLOCK_ROWS, split, cpu_frames, W, H),
+                      "gpu_side": "every rank's timed tracer itself (same context and schedule: %d frames per launch, %d stream(s)), restarted"
+                                  % (batch, streams) + ("" if world > 1 else "; --share-of: rank 0's rows only"),
+                      "mse": max(e["mse"] for e in every), "bit_exact": all(e["bit_exact"] for e in every),
+                      "live_equal": all(e["live_equal"] for e in every), "rays_equal": all(e["rays_equal"] for e in every),
+                      "ranks": every, "tolerance_mse": 1e-4}
 
     if rank != 0:
         return None
     value = rays / elapsed / 1e6
+    roofline["frame_level_frac"] = (roofline.get("frame_level") or {}).get("frac")
+    if steady is not None:
+        roofline["steady_state_frame_level_frac"] = steady["frame_level_frac"]
     return {
         "metric": "Mrays/s at 1920×1080, 8 bounces", "value": round(value, 3), "unit": "Mrays/s",
+        "mrays_per_s_walked": round(walked_total / elapsed / 1e6, 3),
+        "value_note": "value counts every closest-hit query (SURVEY 8d); mrays_per_s_walked counts only the rays the traversal launches "
+                      "fetched: primary rays whose three world-box tests in k_raygen already say 'sky' are answered there "
+                      "(roofline.rays_answered_by_the_list_builder) and never walk the tree",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -531,7 +612,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         "roofline": roofline,
         "gather": gather,
         "ranks": ranks_detail or None,
-        "rccl_ranks": (0 if rehearse else world) if world > 1 else None,
+        "rccl_ranks": rccl_ranks, "distinct_devices": distinct_devices,
         "parity": parity,
         "steady_state": steady,
         "latency": latency,
@@ -587,16 +668,35 @@ def run_config2(args, pkg, torch, local_rank):
     roofline["kernel"] = roofline["kernel"].replace("k_traverse4 (", "k_traverse4m (both instances of the mesh in one launch per bounce; ")
     roofline["note"] = ("%.1f node visits per ray: the fixed round trips of a ray (fetch, root, winner's parent box and normal, store) "
                         "weigh more than its walk" % roofline["node_visits_per_ray"])
+    roofline["frame_level_frac"] = (roofline.get("frame_level") or {}).get("frac")
+    cpu_baseline = parity = None
+    cpu_frames = max(1, min(args.cpu_frames, 4, args.steps))
+    if not args.no_cpu_baseline:
+        # the tracer that was just timed, restarted, for the iterations the oracle renders below
+        pt.restart()
+        r0 = pt.stats()["rays_total"]
+        for _ in range(cpu_frames):
+            pt.path_trace(scene.camera)
+        got = {k: pt.download(k) for k in ("color", "normal", "depth")}
+        st = pt.stats()
+        got["rays"], got["last_live"] = st["rays_total"] - r0, st["last_live"]
     pt.close()
-    cpu_baseline = None
     if not args.no_cpu_baseline:
         orc = graft.load_oracle()
         cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
         t0 = time.perf_counter()
-        ref = orc.render_streaming(flat, scene.camera, W, H, 0, 2, MB, nthreads=cores)
+        ref = orc.render_streaming(flat, scene.camera, W, H, 0, cpu_frames, MB, nthreads=cores)
         dt = time.perf_counter() - t0
         cpu_baseline = {"value": round(ref["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                        "sample": f"2 frames of the same scene at {W}x{H}: {ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so"}
+                        "sample": f"{cpu_frames} accumulated iterations of the same scene at {W}x{H}: {ref['rays']} rays in {dt:.2f} s; "
+                                  "oracle/liboracle.so (CPU restatement; the reference has no CPU path)"}
+        d = got["color"].astype(np.float64) - ref["color"].astype(np.float64)
+        parity = {"against": "the CPU oracle's %d accumulated iterations at %dx%d (the frames of cpu_baseline)" % (cpu_frames, W, H),
+                  "gpu_side": "the timed tracer itself (same context and schedule: %d frames per launch, %d streams), restarted" % (batch, streams),
+                  "mse": float(np.mean(np.sum(d * d, axis=-1))),
+                  "bit_exact": bool(all(np.array_equal(got[k], ref[k]) for k in ("color", "normal", "depth"))),
+                  "live_equal": bool(got["last_live"][:MB] == [int(v) for v in ref["live"][-1][:MB]]),
+                  "rays_equal": bool(got["rays"] == ref["rays"]), "tolerance_mse": 1e-4}
     return {
         "metric": "Mrays/s at 1280×720, 8 bounces (config 2)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -606,7 +706,7 @@ def run_config2(args, pkg, torch, local_rank):
                    "triangles": len(flat.indices) // 3, "instances": 2, "bvh_depth": int(bvh_depth), "resolution": [W, H],
                    "max_bounces": MB, "frames_in_flight": streams * batch, "frames_per_launch": batch,
                    "rays_per_step": round(rays / args.steps), "live_per_bounce_last_frame_rank0": last_live},
-        "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "roofline": roofline, "parity": parity, "cpu_baseline": cpu_baseline,
     }
 
 
@@ -620,7 +720,9 @@ def run_config5(args, pkg, torch, local_rank):
     P = W * H
     rgba = torch.empty((H, W), dtype=torch.int32, device="cuda")
 
-    def loop(denoise, steps, warmup, events):
+    checked = {}
+
+    def loop(denoise, steps, warmup, events, keep=False):
         pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
         pt.set_param("frames_in_flight", 4)   # a present after every iteration leaves no room for more
         pt.set_param("batch_frames", 2)
@@ -652,10 +754,16 @@ def run_config5(args, pkg, torch, local_rank):
         el = time.perf_counter() - t0
         rays = pt.stats()["rays_total"] - rays0
         prof = pt.profile()
+        if keep:   # what the last timed frame left on the device: iteration 0, denoised -- compared with the oracle below
+            pt.set_profiling(False, False)
+            for k in ("color", "normal", "depth", "final"):
+                checked[k] = pt.download(k)
+            checked["rgba"] = pt.send_to_preview()
+            checked["last_live"] = pt.stats()["last_live"]
         pt.close()
         return el, rays, prof
 
-    el, rays, prof = loop(True, args.steps, args.warmup, not args.no_events)
+    el, rays, prof = loop(True, args.steps, args.warmup, not args.no_events, keep=not args.no_cpu_baseline)
     el_nd, _, _ = loop(False, args.steps, args.warmup, False)
     passes = max(prof["denoise_passes"], 1)
     den_ms_pass = prof["denoise_ms"] / passes
@@ -666,6 +774,33 @@ def run_config5(args, pkg, torch, local_rank):
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "pricing": "(48 B read + 16 B written) per pixel and pass", "launches": prof["denoise_passes"],
                 "avg_launch_us": round(den_ms_pass * 1e3, 2), "alg_bytes_per_launch": pass_bytes}
+    cpu_baseline = parity = None
+    if not args.no_cpu_baseline:
+        # the same frame on the host: one iteration, the four A-Trous passes, the tonemap -- timed (cpu_baseline) and compared
+        # with what the timed loop's LAST frame left on the device (every frame of the loop is iteration 0 of the same camera)
+        orc = graft.load_oracle()
+        cores = max(1, min(args.cpu_threads, orc.lib().orc_hardware_threads()))
+        t0 = time.perf_counter()
+        ref = orc.render_streaming(flat, scene.camera, W, H, 0, 1, MB, nthreads=cores)
+        t1 = time.perf_counter()
+        den, touched = orc.denoise(scene.camera, W, H, ref["color"], ref["normal"], ref["depth"], nthreads=cores)
+        t2 = time.perf_counter()
+        img = orc.preview(den, W, H, 0)
+        t3 = time.perf_counter()
+        cpu_baseline = {"value": round((t3 - t0) * 1e3, 1), "unit": "ms/frame", "cores": cores, "kind": "port",
+                        "sample": f"ONE frame of the same workload at {W}x{H}: 1 spp ({ref['rays']} rays, {t1 - t0:.2f} s) + 4-pass A-Trous "
+                                  f"({t2 - t1:.2f} s) + tonemap ({t3 - t2:.2f} s); oracle/liboracle.so (CPU restatement; the reference has no CPU path)"}
+        ok = ~touched     # pixels that depend on the reference's out-of-bounds taps are excluded
+        den_err = float(np.max(np.abs(checked["final"][ok] - den[ok])))
+        lsb = int(np.max(np.abs(checked["rgba"][ok].astype(np.int32) - img[ok].astype(np.int32))))
+        parity = {"against": "the CPU oracle's frame: 1 iteration, orc_denoise, orc_preview (the frame of cpu_baseline)",
+                  "gpu_side": "the last frame of the timed loop itself",
+                  "bit_exact": bool(all(np.array_equal(checked[k], ref[k]) for k in ("color", "normal", "depth"))),
+                  "live_equal": bool(checked["last_live"][:MB] == [int(v) for v in ref["live"][-1][:MB]]),
+                  "denoised_max_abs_err": den_err, "tolerance_denoised": 1e-5, "denoised_within_tolerance": bool(den_err <= 1e-5),
+                  "rgba_max_lsb": lsb, "tolerance_rgba_lsb": 1, "pixels_excluded_oob_taps": int(touched.sum()),
+                  "note": "bit_exact: the undenoised colour / normal / depth planes; expf (denoiser) and powf (tonemap) use the platform "
+                          "libraries on both sides, hence tolerances there"}
     return {
         "metric": "ms per frame: 1 spp + A-Trous denoise + present at 1920×1080, 8 bounces (config 5)",
         "value": round(el / args.steps * 1e3, 4), "unit": "ms/frame", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -677,7 +812,7 @@ def run_config5(args, pkg, torch, local_rank):
                    "ms_per_frame_without_denoise": round(el_nd / args.steps * 1e3, 4),
                    "denoise_ms_per_frame_kernel_time": round(prof["denoise_ms"] / args.steps, 4),
                    "denoise_ms_per_pass": round(den_ms_pass, 4), "mrays_per_s": round(rays / el / 1e6, 1)},
-        "roofline": roofline, "cpu_baseline": None,
+        "roofline": roofline, "parity": parity, "cpu_baseline": cpu_baseline,
     }
 
 

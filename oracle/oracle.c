@@ -979,8 +979,31 @@ typedef struct {
   uint32_t bounce;
   uint32_t pix_begin;   /* first pixel of the band (0 for a full frame) */
   uint32_t slot_base;   /* added to the local slot index before RNG seeding (0 for a full frame) */
+  /* interleaved row blocks (orc_render_streaming_interleaved); il_nranks == 0: a contiguous band */
+  uint32_t il_rank, il_nranks, il_block_rows;
   float* fb_color; float* fb_normal; float* fb_depth;
 } StreamCtx;
+
+/* Which pixel of the frame the rank's slot `index` holds at ray generation, and back.  Contiguous band: pix_begin + index.
+ * Interleaved: the frame is cut into blocks of il_block_rows rows, block gb belongs to rank gb % nranks; a rank's rows
+ * are numbered in frame order (its local row lr lies in its (lr / block_rows)-th block). */
+static uint32_t band_slot_to_pixel(const StreamCtx* c, uint32_t index)
+{
+  if (c->il_nranks == 0u) return c->pix_begin + index;
+  const uint32_t W = c->camera.width;
+  const uint32_t local_row = index / W, x = index % W;
+  const uint32_t my_block = local_row / c->il_block_rows, row_in_block = local_row % c->il_block_rows;
+  const uint32_t frame_block = my_block * c->il_nranks + c->il_rank;
+  return (frame_block * c->il_block_rows + row_in_block) * W + x;
+}
+static uint32_t band_pixel_to_local(const StreamCtx* c, uint32_t pixel)
+{
+  if (c->il_nranks == 0u) return pixel - c->pix_begin;
+  const uint32_t W = c->camera.width;
+  const uint32_t y = pixel / W, x = pixel % W;
+  const uint32_t frame_block = y / c->il_block_rows, row_in_block = y % c->il_block_rows;
+  return ((frame_block / c->il_nranks) * c->il_block_rows + row_in_block) * W + x;
+}
 
 static void raygen_range(void* p, uint32_t begin, uint32_t end, int tid)
 {
@@ -988,7 +1011,7 @@ static void raygen_range(void* p, uint32_t begin, uint32_t end, int tid)
   StreamCtx* c = (StreamCtx*)p;
   const uint32_t W = c->camera.width;
   for (uint32_t index = begin; index < end; ++index) {
-    const uint32_t pixel = c->pix_begin + index;
+    const uint32_t pixel = band_slot_to_pixel(c, index);
     const uint32_t x = pixel % W, y = pixel / W;
     uint32_t rng = orc_rng_seed(orc_path_seed(pixel, c->iteration));
     const float fx = (float)x + orc_rng_uniform(&rng);
@@ -1048,7 +1071,7 @@ static void gather_range(void* p, uint32_t begin, uint32_t end, int tid)
   (void)tid;
   StreamCtx* c = (StreamCtx*)p;
   for (uint32_t index = begin; index < end; ++index) {
-    const int pixel_index = c->paths.pixel_indices[index] - (int)c->pix_begin;
+    const int pixel_index = (int)band_pixel_to_local(c, (uint32_t)c->paths.pixel_indices[index]);
     final_gather(c->iteration, c->paths.color_buffer[index], c->paths.normal_buffer[index],
                  c->paths.depth_buffer[index], c->fb_color + 3 * (size_t)pixel_index,
                  c->fb_normal + 3 * (size_t)pixel_index, c->fb_depth + pixel_index);
@@ -1165,6 +1188,60 @@ uint64_t orc_render_streaming_band(const OScene* scene, const OCamera* cam, uint
     paths_count = stable_partition_paths(&c.paths, &tmp, paths_count);
   }
   parallel_for(pixels_count, nthreads, gather_range, &c);
+  free(c.intersections);
+  paths_free(&tmp);
+  paths_free(&c.paths);
+  return rays;
+}
+
+uint32_t orc_interleaved_rows(uint32_t h, uint32_t rank, uint32_t nranks, uint32_t block_rows)
+{
+  if (nranks == 0u || block_rows == 0u || rank >= nranks) return 0u;
+  uint32_t rows = 0;
+  for (uint32_t first = rank * block_rows; first < h; first += nranks * block_rows)
+    rows += h - first < block_rows ? h - first : block_rows;
+  return rows;
+}
+
+/* The multi-GPU split that is benchmarked (no reference equivalent): a rank renders the rows of every nranks-th block
+ * of block_rows rows and numbers its paths locally; the material RNG, which the reference keys on the compacted slot
+ * index (path_tracer.cu:297-301), is keyed on slot_offset + the rank's own compacted slot at EVERY bounce (bounce 0
+ * included, where a full frame would use the pixel index); ray generation stays keyed on the frame's pixel index
+ * (ray_gen.cu:17-22).  Everything else is orc_render_streaming on the rank's pixel set. */
+uint64_t orc_render_streaming_interleaved(const OScene* scene, const OCamera* cam, uint32_t w, uint32_t h, uint32_t rank,
+                                          uint32_t nranks, uint32_t block_rows, uint32_t slot_offset, uint32_t iter_begin,
+                                          uint32_t iter_count, uint32_t max_bounces, float* fb_color, float* fb_normal,
+                                          float* fb_depth, uint32_t* live_counts, int nthreads)
+{
+  const uint32_t pixels_count = orc_interleaved_rows(h, rank, nranks, block_rows) * w;
+  if (pixels_count == 0u) return 0;
+  StreamCtx c;
+  memset(&c, 0, sizeof c);
+  c.scene = scene;
+  orc_to_gpu_camera(cam, w, h, &c.camera);
+  paths_alloc(&c.paths, pixels_count);
+  OPaths tmp;
+  paths_alloc(&tmp, pixels_count);
+  c.intersections = (OIntersection*)malloc(sizeof(OIntersection) * pixels_count);
+  c.fb_color = fb_color; c.fb_normal = fb_normal; c.fb_depth = fb_depth;
+  c.il_rank = rank; c.il_nranks = nranks; c.il_block_rows = block_rows;
+  c.slot_base = slot_offset;
+  uint64_t rays = 0;
+  for (uint32_t it = 0; it < iter_count; ++it) {
+    c.iteration = (uint64_t)iter_begin + it;
+    parallel_for(pixels_count, nthreads, raygen_range, &c);
+    uint32_t paths_count = pixels_count;
+    if (live_counts) memset(live_counts + (size_t)it * max_bounces, 0, sizeof(uint32_t) * max_bounces);
+    for (uint32_t i = 0; i < max_bounces && paths_count > 0; ++i) {
+      if (live_counts) live_counts[(size_t)it * max_bounces + i] = paths_count;
+      rays += paths_count;
+      c.bounce = i;
+      parallel_for(paths_count, nthreads, intersection_range, &c);
+      parallel_for(paths_count, nthreads, material_range, &c);
+      paths_count = stable_partition_paths(&c.paths, &tmp, paths_count);
+    }
+    parallel_for(pixels_count, nthreads, gather_range, &c);
+  }
   free(c.intersections);
   paths_free(&tmp);
   paths_free(&c.paths);

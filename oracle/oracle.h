@@ -156,6 +156,19 @@ uint64_t orc_render_streaming_band(const OScene* scene, const OCamera* cam, uint
                                    float* fb_normal, float* fb_depth, uint32_t* live_counts,
                                    orc_exchange_fn exchange, void* user, int nthreads);
 
+/* The rows of ONE RANK under interleaved row blocks, the split bench.py --gpus N and hip_pt --gpus N run (no reference
+ * equivalent): blocks of block_rows rows dealt round-robin to nranks ranks, paths numbered per rank, the material RNG
+ * (path_tracer.cu:297-301) keyed on slot_offset + the rank's compacted slot index at every bounce; ray generation keyed
+ * on the frame's pixel index as always.  Same semantics as ptc_set_interleave + "slot_offset".  fb_* hold the rank's
+ * rows packed in frame order (orc_interleaved_rows() of them) and the running means over iterations
+ * [iter_begin, iter_begin + iter_count); live_counts as in orc_render_streaming.  A different noise realisation from the
+ * single-GPU frame by construction (rank 0 with nranks 1 and slot_offset 0 IS the single-GPU frame). */
+uint32_t orc_interleaved_rows(uint32_t h, uint32_t rank, uint32_t nranks, uint32_t block_rows);
+uint64_t orc_render_streaming_interleaved(const OScene* scene, const OCamera* cam, uint32_t w, uint32_t h, uint32_t rank,
+                                          uint32_t nranks, uint32_t block_rows, uint32_t slot_offset, uint32_t iter_begin,
+                                          uint32_t iter_count, uint32_t max_bounces, float* fb_color, float* fb_normal,
+                                          float* fb_depth, uint32_t* live_counts, int nthreads);
+
 /* Megakernel mode (path_tracer.cu:227-269). */
 uint64_t orc_render_megakernel(const OScene* scene, const OCamera* cam, uint32_t w, uint32_t h,
                                uint32_t iter_begin, uint32_t iter_count, uint32_t max_bounces,

@@ -93,6 +93,36 @@ def main_multimesh():
     print("wrote", os.path.join(HERE, "multimesh.npz"))
 
 
+INTERLEAVED = dict(w=48, h=72, block_rows=8, max_bounces=8, iterations=3, worlds=(2, 3, 8))
+
+
+def interleaved_scene():
+    """The small heightfield at 48 x 72: nine blocks of 8 rows, so that with 8 ranks rank 0 owns two blocks and the
+    others one, with 3 ranks three each, with 2 ranks five and four."""
+    c = INTERLEAVED
+    return pkg.scenes.heightfield_scene((c["w"], c["h"]), nx=33, nz=17)
+
+
+def main_interleaved():
+    """tests/golden/interleaved.npz: the multi-GPU split that bench.py --gpus N times (interleaved row blocks, paths
+    numbered per rank, "slot_offset" = rank * W * H), every rank of worlds 2 / 3 / 8 rendered by the oracle
+    (orc_render_streaming_interleaved) and assembled into frame order; per-rank live counts and ray totals."""
+    c = INTERLEAVED
+    scene = interleaved_scene()
+    flat = scene.build_scene()
+    w, h = c["w"], c["h"]
+    out = {}
+    for world in c["worlds"]:
+        parts = [orc.render_interleaved(flat, scene.camera, w, h, r, world, c["block_rows"], r * w * h, 0, c["iterations"],
+                                        c["max_bounces"]) for r in range(world)]
+        for k in ("color", "normal", "depth"):
+            out[f"w{world}_{k}"] = pkg.bands.assemble_interleaved([p[k] for p in parts], h, world, c["block_rows"])
+        out[f"w{world}_live"] = np.stack([p["live"] for p in parts])
+        out[f"w{world}_rays"] = np.array([p["rays"] for p in parts], dtype=np.uint64)
+    np.savez_compressed(os.path.join(HERE, "interleaved.npz"), **out)
+    print("wrote", os.path.join(HERE, "interleaved.npz"))
+
+
 def main():
     out = {}
     for name, (scene, w, h) in golden_scenes().items():
@@ -151,6 +181,9 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["multimesh"]:     # only the multi-mesh fixtures (the others stay as committed)
         main_multimesh()
+    elif sys.argv[1:] == ["interleaved"]:
+        main_interleaved()
     else:
         main()
         main_multimesh()
+        main_interleaved()

@@ -1,7 +1,9 @@
 """Worker of tests/test_gpu_multiprocess.py: one of N processes that share cuda:0 (torch.distributed over gloo, started
 by torch.distributed.run).  Renders a row band with GLOBAL slot numbering (live counts exchanged per bounce) and sends
 its rows to rank 0 through the library's inter-process gather; rank 0 compares the assembled frame with a
-single-context render of the same scene, bit for bit, and then does the same for the interleaved split."""
+single-context render of the same scene, bit for bit.  Then the interleaved split with per-rank numbering (what bench.py
+--gpus N runs): the frame the library gathers on rank 0 must be, bit for bit, the CPU oracle's rendering of every rank's
+rows (orc_render_streaming_interleaved) put into frame order."""
 import os
 import sys
 
@@ -71,7 +73,8 @@ def main():
     pt.close()
 
     # --- interleaved row blocks, local numbering with a per-rank slot offset (what bench.py and hip_pt --gpus run):
-    #     the first-hit G-buffer is the single-GPU one exactly, the radiance the same up to noise
+    #     every rank's rows bit-identical to the oracle's rendering of that rank, through the library's gather; the
+    #     first-hit G-buffer is also the single-GPU one exactly
     pt = pkg.PathTracer(device=0, max_bounces=MB)
     pt.set_param("frames_in_flight", 4)
     pt.set_param("batch_frames", 2)
@@ -88,9 +91,15 @@ def main():
         if not (np.array_equal(got["normal"], want["normal"]) and np.array_equal(got["depth"], want["depth"])):
             print("MISMATCH interleaved G-buffer", flush=True)
             ok = False
-        if abs(float(got["color"].mean()) - float(want["color"].mean())) > 0.01:
-            print("MISMATCH interleaved mean radiance", flush=True)
-            ok = False
+        orc = graft.load_oracle()
+        sh = orc.SceneHandle(flat)
+        parts = [orc.render_interleaved(flat, scene.camera, W, H, r, world, 8, r * W * H if world > 1 else 0, 0, ITERS, MB,
+                                        scene_handle=sh) for r in range(world)]
+        for k in ("color", "normal", "depth"):
+            oracle_frame = pkg.bands.assemble_interleaved([p[k] for p in parts], H, world, 8)
+            if not np.array_equal(got[k], oracle_frame):
+                print(f"MISMATCH interleaved {k} vs oracle: {int(np.sum(got[k] != oracle_frame))} values differ", flush=True)
+                ok = False
     pt.close()
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)

@@ -108,6 +108,11 @@ def lib():
         h.orc_render_streaming_band.argtypes = [C.POINTER(OScene), C.POINTER(OCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, EXCHANGE_FN, C.c_void_p, C.c_int]
+        h.orc_interleaved_rows.restype = C.c_uint32
+        h.orc_interleaved_rows.argtypes = [C.c_uint32] * 4
+        h.orc_render_streaming_interleaved.restype = C.c_uint64
+        h.orc_render_streaming_interleaved.argtypes = [C.POINTER(OScene), C.POINTER(OCamera)] + [C.c_uint32] * 9 + \
+                                                       [C.c_void_p] * 4 + [C.c_int]
         h.orc_render_megakernel.restype = C.c_uint64
         h.orc_render_megakernel.argtypes = [C.POINTER(OScene), C.POINTER(OCamera), C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -229,12 +234,35 @@ def render_band(flat, camera, w, h, rows, iteration, max_bounces, exchange=None,
     return {"color": color, "normal": normal, "depth": depth, "live": live, "rays": int(rays)}
 
 
-def render_megakernel(flat, camera, w, h, iter_begin, iter_count, max_bounces, nthreads=0):
-    sh = SceneHandle(flat)
+def render_interleaved(flat, camera, w, h, rank, nranks, block_rows, slot_offset, iter_begin, iter_count, max_bounces,
+                       nthreads=0, prev=None, scene_handle=None):
+    """The rows of rank `rank` under interleaved row blocks (ptc_set_interleave + "slot_offset"), packed in frame order:
+    running means over iterations [iter_begin, iter_begin + iter_count)."""
+    sh = scene_handle or SceneHandle(flat)
     cam = camera_c(camera)
-    color = np.zeros((h, w, 3), dtype=np.float32)
-    normal = np.zeros((h, w, 3), dtype=np.float32)
-    depth = np.zeros((h, w), dtype=np.float32)
+    rows = int(lib().orc_interleaved_rows(h, rank, nranks, block_rows))
+    if prev is None:
+        color = np.zeros((rows, w, 3), dtype=np.float32)
+        normal = np.zeros((rows, w, 3), dtype=np.float32)
+        depth = np.zeros((rows, w), dtype=np.float32)
+    else:
+        color, normal, depth = (np.array(prev[k], dtype=np.float32, copy=True) for k in ("color", "normal", "depth"))
+    live = np.zeros((iter_count, max_bounces), dtype=np.uint32)
+    rays = lib().orc_render_streaming_interleaved(C.byref(sh.c), C.byref(cam), w, h, rank, nranks, block_rows, slot_offset,
+                                                  iter_begin, iter_count, max_bounces, color.ctypes.data, normal.ctypes.data,
+                                                  depth.ctypes.data, live.ctypes.data, nthreads)
+    return {"color": color, "normal": normal, "depth": depth, "live": live, "rays": int(rays)}
+
+
+def render_megakernel(flat, camera, w, h, iter_begin, iter_count, max_bounces, nthreads=0, prev=None, scene_handle=None):
+    sh = scene_handle or SceneHandle(flat)
+    cam = camera_c(camera)
+    if prev is None:
+        color = np.zeros((h, w, 3), dtype=np.float32)
+        normal = np.zeros((h, w, 3), dtype=np.float32)
+        depth = np.zeros((h, w), dtype=np.float32)
+    else:
+        color, normal, depth = (np.array(prev[k], dtype=np.float32, copy=True) for k in ("color", "normal", "depth"))
     rays = lib().orc_render_megakernel(C.byref(sh.c), C.byref(cam), w, h, iter_begin, iter_count, max_bounces,
                                        color.ctypes.data, normal.ctypes.data, depth.ctypes.data, nthreads)
     return {"color": color, "normal": normal, "depth": depth, "rays": int(rays)}

@@ -2,7 +2,10 @@
 (interactive-app/first_person_camera_controller.cpp:12-100) restated in C++ (host/first_person_camera_controller.hpp)
 and Python (camera_controller.py), and its frame loop (app.cpp:141-170) replayed from a script of viewer events by
 `hip_pt --replay` and `viewer.replay`.  CPU: the controller's arithmetic against hand-computed values and the two
-implementations against each other; GPU: the PNG sequence of the C++ replay equals the frames of the Python replay."""
+implementations against each other; GPU: the PNG sequence of the C++ replay equals the frames of the Python replay, and
+every displayed frame equals what the CPU oracle renders for the viewer's state at that turn (`oracle_replay`: the
+reference's PathTracer semantics -- iteration counter, max_iterations, restart, resize, method, denoise, display type,
+path_tracer.cu:389-525 -- over orc_render_streaming / orc_render_megakernel / orc_denoise / orc_preview)."""
 import json
 import os
 import subprocess
@@ -119,6 +122,129 @@ def test_cpp_controller_equals_python(pkg, tmp_path):
         assert int(lines[k][-1]) == restarts, ev
         k += 1
     assert k == len(lines) and restarts == 12
+
+
+def oracle_replay(pkg, orc, scene, script, max_bounces):
+    """The viewer loop (app.cpp:141-170, gui.cpp:84-108) with the CPU oracle in the place of the GPU: the state a
+    `PathTracer` keeps between calls, restated from path_tracer.cu -- `path_trace` renders iteration_ and counts it only
+    while iteration_ < max_iterations and always re-points the result at the colour buffer (:391,:476); `denoise` filters
+    the ACCUMULATED buffers and makes its output the result (:479-485); `restart` zeroes the counter (:522-525);
+    `resize_image` reallocates and restarts (:527-545); `send_to_preview` shows the result, the normals or 1/depth
+    (:487-520).  Returns [(rgba, exact_mask)]: exact_mask marks the pixels whose value does not depend on the reference's
+    out-of-bounds A-Trous taps (all of them for an undenoised frame)."""
+    import copy
+    window = tuple(int(v) for v in script.get("window", (800, 800)))
+    per_frame = int(script.get("iterations_per_frame", 1))
+    camera = copy.copy(scene.camera)
+    controller = pkg.camera_controller.FirstPersonCameraController(camera)
+    flat = scene.build_scene()
+    sh = orc.SceneHandle(flat)
+    st = {"iteration": 0, "max_iterations": scene.spp, "method": "streaming", "denoise": False, "display": "final",
+          "res": window, "fb": None, "result": None, "touched": None}
+    shown = []
+
+    def path_trace():
+        w, h = st["res"]
+        if st["iteration"] < st["max_iterations"]:
+            render = orc.render_megakernel if st["method"] == "megakernel" else orc.render_streaming
+            prev = st["fb"] if st["iteration"] > 0 else None
+            st["fb"] = render(flat, camera, w, h, st["iteration"], 1, max_bounces, prev=prev, scene_handle=sh)
+            st["iteration"] += 1
+        st["result"], st["touched"] = st["fb"]["color"], None
+
+    def denoise():
+        w, h = st["res"]
+        fb = st["fb"]
+        st["result"], st["touched"] = orc.denoise(camera, w, h, fb["color"], fb["normal"], fb["depth"])
+
+    def turn():
+        for _ in range(per_frame):
+            path_trace()
+            if st["denoise"]:
+                denoise()
+        w, h = st["res"]
+        exact = np.ones((h, w), dtype=bool)
+        if st["display"] == "normal":
+            rgba = orc.preview(st["fb"]["normal"], w, h, 1)
+        elif st["display"] == "depth":
+            rgba = orc.preview(st["fb"]["depth"], w, h, 2)
+        else:
+            rgba = orc.preview(st["result"], w, h, 0)
+            if st["touched"] is not None:
+                exact = ~st["touched"]
+        shown.append((rgba, exact, st["touched"] is not None))
+
+    radians = np.float32(np.radians(1))
+    for ev in script["events"]:
+        if "frames" in ev:
+            for _ in range(int(ev["frames"])):
+                turn()
+        elif "key" in ev:
+            for _ in range(int(ev.get("count", 1))):
+                if controller.on_key_press(ev["key"][:1]):
+                    st["iteration"] = 0
+        elif "mouse" in ev:
+            if controller.on_mouse_move(radians * np.float32(ev["mouse"][0]), radians * np.float32(ev["mouse"][1])):
+                st["iteration"] = 0
+        elif "space" in ev:
+            st["iteration"] = 0
+        elif "resize" in ev:
+            st["res"], st["iteration"] = tuple(int(v) for v in ev["resize"]), 0
+        elif "denoise" in ev:
+            st["denoise"] = bool(ev["denoise"])
+        elif "display" in ev:
+            st["display"] = ev["display"]
+        elif "method" in ev:
+            st["method"] = ev["method"]
+        elif "max_iterations" in ev:
+            st["max_iterations"] = max(1, int(ev["max_iterations"]))
+        elif "speed" in ev:
+            controller.speed = np.float32(ev["speed"])
+        elif "position" in ev:
+            controller.set_position(ev["position"])
+            controller.update_camera()
+            st["iteration"] = 0
+        elif "reset" in ev:
+            controller.reset()
+            st["iteration"] = 0
+        else:
+            raise ValueError(ev)
+    return shown
+
+
+@pytest.mark.gpu
+def test_replay_frames_against_the_oracle(pkg, orc):
+    """Every frame the replayed viewer displays, against the CPU oracle driven through the same script: exact for
+    undenoised frames (final, normal view, megakernel), within 1 LSB for denoised ones on the pixels that do not
+    depend on the reference's out-of-bounds taps.  Round 3 compared the two front-ends with each
+    other only -- the same HIP path twice."""
+    scene = pkg.json_parser.scene_from_json(os.path.join(ROOT, "assets", "scenes", "cornell_mesh.json"))
+    frames, _ = pkg.viewer.replay(scene, SCRIPT, max_bounces=6)
+    want = oracle_replay(pkg, orc, scene, SCRIPT, 6)
+    assert len(frames) == len(want) == 12
+    denoised_frames = 0
+    for i, (got, (rgba, exact, denoised)) in enumerate(zip(frames, want)):
+        assert got.shape == rgba.shape, i
+        if denoised:
+            denoised_frames += 1
+            assert exact.mean() > 0.25, i            # enough pixels left to mean something
+            diff = np.abs(got.astype(np.int32) - rgba.astype(np.int32))[exact]
+            assert int(diff.max()) <= 1, (i, int(diff.max()))
+            assert float((diff > 0).mean()) < 0.02, i
+        else:
+            assert np.array_equal(got, rgba), (i, int(np.sum(got != rgba)))
+    assert denoised_frames == 4                      # three turns with max_iterations reached + the megakernel frame
+    # a second script: depth view, a filter of one pass, budget-free turns of one iteration at the scene's own spp
+    script2 = {"window": [56, 40], "iterations_per_frame": 1, "events": [
+        {"max_iterations": 4}, {"frames": 2}, {"display": "depth"}, {"frames": 1}, {"display": "final"}, {"mouse": [-35, 12]},
+        {"frames": 1}, {"method": "megakernel"}, {"frames": 2}, {"key": "S", "count": 4}, {"method": "streaming"}, {"frames": 5}]}
+    frames, _ = pkg.viewer.replay(scene, script2, max_bounces=5)
+    want = oracle_replay(pkg, orc, scene, script2, 5)
+    assert len(frames) == len(want) == 11
+    for i, (got, (rgba, exact, denoised)) in enumerate(zip(frames, want)):
+        assert not denoised and np.array_equal(got, rgba), (i, int(np.sum(got != rgba)))
+    assert np.all(frames[2][..., 3] == 1)            # the depth view's alpha (path_tracer.cu:345-354)
+    assert np.array_equal(frames[-1], frames[-2])    # max_iterations 4 reached after four of the five turns
 
 
 @pytest.mark.gpu
