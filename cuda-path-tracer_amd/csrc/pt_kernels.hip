@@ -1110,6 +1110,18 @@ struct BatchFeed {
 #endif
 
 
+// -DPT_TAILPROF (diagnostic builds only, tools/tailprof.py): per traversal launch and wavefront the times (100 MHz
+// wall clock) at which it started, found the feed exhausted and left the loop, and its loop iterations / split rounds
+// taken -- where does the end of a launch go?
+#ifdef PT_TAILPROF
+__device__ unsigned long long g_tailprof[16][8192][4];
+extern "C" int ptc_debug_tailprof(void* dst, size_t bytes)
+{
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tailprof), bytes < sizeof(g_tailprof) ? bytes : sizeof(g_tailprof)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll
@@ -1175,6 +1187,11 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
   const f3 obj_bmin = mk3(uni(obj->bmin[0]), uni(obj->bmin[1]), uni(obj->bmin[2]));
   const f3 obj_bmax = mk3(uni(obj->bmax[0]), uni(obj->bmax[1]), uni(obj->bmax[2]));
+#ifdef PT_TAILPROF
+  const unsigned long long tp_start = wall_clock64();
+  unsigned long long tp_exhausted = 0ull;
+  uint32_t tp_iters = 0u, tp_splits = 0u;
+#endif
   BatchFeed feed;
   feed.init(counters, bi, bounce, work_slot, sc.static_eighths, listed);
   uint32_t priv_next = 0u, priv_end = 0u;
@@ -1367,6 +1384,10 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     const uint64_t idle_mask = __ballot(!active);
     const uint32_t idle = (uint32_t)__popcll(idle_mask);
     const bool more = priv_next < priv_end || !feed.exhausted();
+#ifdef PT_TAILPROF
+    ++tp_iters;
+    if (!more && tp_exhausted == 0ull) tp_exhausted = wall_clock64();
+#endif
     if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
       if (pending) {
         retire();
@@ -1452,6 +1473,9 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         pending = false;
       }
       split();
+#ifdef PT_TAILPROF
+      ++tp_splits;
+#endif
     }
     if (__ballot(active) == 0ull) {
       if (priv_next >= priv_end && feed.exhausted()) {
@@ -1626,6 +1650,15 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       }
     }
   }
+#ifdef PT_TAILPROF
+  if (threadIdx.x == 0u && blockIdx.x < 8192u && bounce < 16) {
+    unsigned long long* tp = g_tailprof[bounce][blockIdx.x];
+    tp[0] = tp_start;
+    tp[1] = tp_exhausted;
+    tp[2] = wall_clock64();
+    tp[3] = ((unsigned long long)tp_iters << 32) | tp_splits;
+  }
+#endif
   if (flags) atomicOr(&counters->flags, flags);
   if (kCount) flush_tally(tally, counters, bounce, false);
 }
