@@ -1102,6 +1102,13 @@ struct BatchFeed {
 #ifndef PT_SPLIT_EVERY
 #define PT_SPLIT_EVERY 1u
 #endif
+// end of a launch: finished lanes are retired when this many wait, or every so many iterations
+#ifndef PT_RETIRE_LANES
+#define PT_RETIRE_LANES 4u
+#endif
+#ifndef PT_RETIRE_EVERY
+#define PT_RETIRE_EVERY 3u
+#endif
 #ifndef PT_FULL_SORT
 #define PT_FULL_SORT 1
 #endif
@@ -1114,10 +1121,15 @@ struct BatchFeed {
 // wall clock) at which it started, found the feed exhausted and left the loop, and its loop iterations / split rounds
 // taken -- where does the end of a launch go?
 #ifdef PT_TAILPROF
-__device__ unsigned long long g_tailprof[16][8192][4];
+__device__ unsigned long long g_tailprof[16][8192][8];
 extern "C" int ptc_debug_tailprof(void* dst, size_t bytes)
 {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (!dst) {  // clear
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tailprof)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(g_tailprof)) == hipSuccess && hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+  }
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tailprof), bytes < sizeof(g_tailprof) ? bytes : sizeof(g_tailprof)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -1190,7 +1202,8 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
 #ifdef PT_TAILPROF
   const unsigned long long tp_start = wall_clock64();
   unsigned long long tp_exhausted = 0ull;
-  uint32_t tp_iters = 0u, tp_splits = 0u;
+  uint32_t tp_iters = 0u, tp_splits = 0u, tp_iters_exh = 0u, tp_lanes_exh = 0u;
+  unsigned long long tp_c_split = 0ull, tp_c_retire = 0ull, tp_c_step = 0ull, tp_lanes_tail = 0ull;
 #endif
   BatchFeed feed;
   feed.init(counters, bi, bounce, work_slot, sc.static_eighths, listed);
@@ -1201,7 +1214,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   uint32_t slot = 0u, cur = 0u, flags = 0u;
   int sp = 0, sbase = 0, best_k = -1;  // the lane's stack is entries [sbase, sp) of its column
   bool split_mode = false;             // wave-uniform: some ray of this wavefront is walked by several lanes
-  uint32_t since_split = 0u;
+  uint32_t since_split = 0u, since_retire = 0u;
   f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   f3 oin = mk3(0, 0, 0), oif = mk3(0, 0, 0);
   bool neg_x = false, neg_y = false, neg_z = false;  // sign of 1/d per axis: which plane of a box is the near one
@@ -1333,18 +1346,18 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       adopt(seen);
     }
     const bool can_give = active && sp - sbase >= 1 && sbase < lds_cap;
-    const uint64_t donors = __ballot(can_give), takers = __ballot(!active);
+    const uint64_t donors = __ballot(can_give), takers = __ballot(!active && !pending);
     const uint32_t pairs = min((uint32_t)__popcll(donors), (uint32_t)__popcll(takers));
     if (pairs == 0u) return;
     if (!split_mode) {  // first split of this wavefront: every lane leads its own ray
       s_leader[threadIdx.x] = threadIdx.x;
-      s_grp_count[threadIdx.x] = active ? 1u : 0u;
+      s_grp_count[threadIdx.x] = active || pending ? 1u : 0u;  // (a finished lane that has not retired yet still owes its ray's result)
       s_grp_best[threadIdx.x] = ~0ull;
       split_mode = true;
     }
     const uint32_t drank = rank_below(donors), trank = rank_below(takers);
     if (can_give && drank < pairs) s_pair[drank] = threadIdx.x;
-    const bool take = !active && trank < pairs;
+    const bool take = !active && !pending && trank < pairs;
     const uint32_t d = take ? s_pair[trank] : threadIdx.x;  // my donor (myself: no change)
     // the donor's ray and walk state (every lane reads its partner's registers)
     auto from = [&](float v) { return __shfl(v, (int)d, kWave); };
@@ -1380,114 +1393,8 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     if (can_give && drank < pairs) ++sbase;
   };
 
-  for (;;) {
-    const uint64_t idle_mask = __ballot(!active);
-    const uint32_t idle = (uint32_t)__popcll(idle_mask);
-    const bool more = priv_next < priv_end || !feed.exhausted();
-#ifdef PT_TAILPROF
-    ++tp_iters;
-    if (!more && tp_exhausted == 0ull) tp_exhausted = wall_clock64();
-#endif
-    if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
-      if (pending) {
-        retire();
-        pending = false;
-      }
-      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
-      const uint32_t mine = priv_next + rank_below(idle_mask);
-      const uint32_t range_end = priv_end;
-      priv_next = min(priv_end, priv_next + idle);
-      if (!active && mine < range_end) {
-        slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
-        const float4 o4 = ldnt(&paths.o4[slot]);
-        const float4 d4 = ldnt(&paths.d4[slot]);
-        ro = xyz(o4);
-        rd = xyz(d4);
-        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
-        float t_in = FLT_MAX;
-        if (!kFirst) {
-          const float carried = ldnt(&hits.tp[slot]).x;
-          if (carried >= 0.0f) t_in = carried;
-        }
-        bool go = sc.cur.bvh_node_count != 0u;
-        bool wrote = false;
-        if (go) {
-          // inverse_transform_ray (transform.hpp:51-58) for the walk only: the walk has to be conservative, not
-          // exact, so the normalisation and the reciprocals are the hardware approximations (1 ulp) and the
-          // error bound below covers them; everything that decides the result is recomputed exactly in finalize
-          const f3 v = xform_vector(obj->inv_m, rd);
-          const float len2 = dot(v, v);
-          const float rlen = __builtin_amdgcn_rsqf(len2);
-          scale = len2 * rlen;
-          const f3 od = v * rlen;
-          // the origin in object space for the walk: the reference's (M^-1 (o,1)).xyz / w with the division by w
-          // (1 for an affine transform) as a reciprocal -- finalize recomputes the exact one where it decides
-          const f4 ow = mul(obj->inv_m, ro.x, ro.y, ro.z, 1.0f);
-          const f3 oo_walk = mk3(ow.x, ow.y, ow.z) * __builtin_amdgcn_rcpf(ow.w);
-          inv = mk3(__builtin_amdgcn_rcpf(od.x), __builtin_amdgcn_rcpf(od.y), __builtin_amdgcn_rcpf(od.z));
-          // Slab form t = fma(b, 1/d, -o/d).  Against the reference's (b - o)/d (d normalised with IEEE sqrt and
-          // divide) it is off by at most ~1e-6 of |b/d| + |o/d| per axis (rsq, rcp: 1 ulp each, three roundings);
-          // four times that bound (|b| <= the root box) is folded into the two origin terms so the near side
-          // can only move nearer and the far side farther.
-          const f3 oi = mk3(-(oo_walk.x * inv.x), -(oo_walk.y * inv.y), -(oo_walk.z * inv.z));
-          const float bx = fmaxf(fabsf(sc.cur.root_min[0]), fabsf(sc.cur.root_max[0]));
-          const float by = fmaxf(fabsf(sc.cur.root_min[1]), fabsf(sc.cur.root_max[1]));
-          const float bz = fmaxf(fabsf(sc.cur.root_min[2]), fabsf(sc.cur.root_max[2]));
-          const f3 tol = mk3(4e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
-                             4e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
-                             4e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
-          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z) && finite_f(tol.x + tol.y + tol.z)) ||
-                               sc.force_slow == 1u, 0)) {
-            // degenerate direction (0/0 or overflow in the slab terms voids the error bound): set aside for
-            // the launch's epilogue (redo_slow_rays), which takes every box decision with the reference's own test
-            set_aside(counters, slow_list, slot);
-            wrote = true;
-            go = false;
-          } else {
-            oin = oi - tol;
-            oif = oi + tol;
-            neg_x = inv.x < 0.0f;
-            neg_y = inv.y < 0.0f;
-            neg_z = inv.z < 0.0f;
-            best_t = t_in;
-            best_k = -1;
-            limit = scale * best_t * 1.001f;
-            cur = sc.cur.bvh4_root;
-            sp = sbase = 0;
-            ray_boxes = 0u;
-            if (split_mode) {  // (only when rays are still handed out after a split: never in practice)
-              s_leader[threadIdx.x] = threadIdx.x;
-              s_grp_count[threadIdx.x] = 1u;
-              s_grp_best[threadIdx.x] = ~0ull;
-            }
-          }
-        }
-        if (go) active = true;
-        else if (kFirst && !wrote) stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
-      }
-    } else if (!more && sc.split_idle != 0u && idle >= sc.split_idle && ++since_split >= PT_SPLIT_EVERY) {
-      // nothing left to fetch: idle lanes help the busy ones (every PT_SPLIT_EVERY-th iteration)
-      since_split = 0u;
-      if (pending) {
-        retire();
-        pending = false;
-      }
-      split();
-#ifdef PT_TAILPROF
-      ++tp_splits;
-#endif
-    }
-    if (__ballot(active) == 0ull) {
-      if (priv_next >= priv_end && feed.exhausted()) {
-        if (pending) {
-          retire();
-          pending = false;
-        }
-        break;
-      }
-      continue;
-    }
-
+  // One step of every active lane (the body of both loops below)
+  auto step = [&]() {
     // One loop iteration = one step per lane, and ONE memory round trip: the lane's current reference is either a
     // node or a leaf, both records are fetched by the SAME four 16-byte loads from a per-lane address (a 64-byte
     // node, or a 48-byte triangle record whose last 16 bytes are simply requested twice), and the stack entry the
@@ -1649,6 +1556,146 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         pending = true;
       }
     }
+  };
+
+  for (;;) {
+    const uint64_t idle_mask = __ballot(!active);
+    const uint32_t idle = (uint32_t)__popcll(idle_mask);
+    const bool more = priv_next < priv_end || !feed.exhausted();
+#ifdef PT_TAILPROF
+    ++tp_iters;
+#endif
+    if (!more) break;  // nothing left to fetch: the lanes still walking finish in the second loop
+    if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
+      if (pending) {
+        finalize();  // (no ray is shared between lanes before the second loop)
+        pending = false;
+      }
+      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
+      const uint32_t mine = priv_next + rank_below(idle_mask);
+      const uint32_t range_end = priv_end;
+      priv_next = min(priv_end, priv_next + idle);
+      if (!active && mine < range_end) {
+        slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
+        const float4 o4 = ldnt(&paths.o4[slot]);
+        const float4 d4 = ldnt(&paths.d4[slot]);
+        ro = xyz(o4);
+        rd = xyz(d4);
+        tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
+        float t_in = FLT_MAX;
+        if (!kFirst) {
+          const float carried = ldnt(&hits.tp[slot]).x;
+          if (carried >= 0.0f) t_in = carried;
+        }
+        bool go = sc.cur.bvh_node_count != 0u;
+        bool wrote = false;
+        if (go) {
+          // inverse_transform_ray (transform.hpp:51-58) for the walk only: the walk has to be conservative, not
+          // exact, so the normalisation and the reciprocals are the hardware approximations (1 ulp) and the
+          // error bound below covers them; everything that decides the result is recomputed exactly in finalize
+          const f3 v = xform_vector(obj->inv_m, rd);
+          const float len2 = dot(v, v);
+          const float rlen = __builtin_amdgcn_rsqf(len2);
+          scale = len2 * rlen;
+          const f3 od = v * rlen;
+          // the origin in object space for the walk: the reference's (M^-1 (o,1)).xyz / w with the division by w
+          // (1 for an affine transform) as a reciprocal -- finalize recomputes the exact one where it decides
+          const f4 ow = mul(obj->inv_m, ro.x, ro.y, ro.z, 1.0f);
+          const f3 oo_walk = mk3(ow.x, ow.y, ow.z) * __builtin_amdgcn_rcpf(ow.w);
+          inv = mk3(__builtin_amdgcn_rcpf(od.x), __builtin_amdgcn_rcpf(od.y), __builtin_amdgcn_rcpf(od.z));
+          // Slab form t = fma(b, 1/d, -o/d).  Against the reference's (b - o)/d (d normalised with IEEE sqrt and
+          // divide) it is off by at most ~1e-6 of |b/d| + |o/d| per axis (rsq, rcp: 1 ulp each, three roundings);
+          // four times that bound (|b| <= the root box) is folded into the two origin terms so the near side
+          // can only move nearer and the far side farther.
+          const f3 oi = mk3(-(oo_walk.x * inv.x), -(oo_walk.y * inv.y), -(oo_walk.z * inv.z));
+          const float bx = fmaxf(fabsf(sc.cur.root_min[0]), fabsf(sc.cur.root_max[0]));
+          const float by = fmaxf(fabsf(sc.cur.root_min[1]), fabsf(sc.cur.root_max[1]));
+          const float bz = fmaxf(fabsf(sc.cur.root_min[2]), fabsf(sc.cur.root_max[2]));
+          const f3 tol = mk3(4e-6f * (fabsf(oi.x) + bx * fabsf(inv.x)) + 1e-30f,
+                             4e-6f * (fabsf(oi.y) + by * fabsf(inv.y)) + 1e-30f,
+                             4e-6f * (fabsf(oi.z) + bz * fabsf(inv.z)) + 1e-30f);
+          if (__builtin_expect(!(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z) && finite_f(tol.x + tol.y + tol.z)) ||
+                               sc.force_slow == 1u, 0)) {
+            // degenerate direction (0/0 or overflow in the slab terms voids the error bound): set aside for
+            // the launch's epilogue (redo_slow_rays), which takes every box decision with the reference's own test
+            set_aside(counters, slow_list, slot);
+            wrote = true;
+            go = false;
+          } else {
+            oin = oi - tol;
+            oif = oi + tol;
+            neg_x = inv.x < 0.0f;
+            neg_y = inv.y < 0.0f;
+            neg_z = inv.z < 0.0f;
+            best_t = t_in;
+            best_k = -1;
+            limit = scale * best_t * 1.001f;
+            cur = sc.cur.bvh4_root;
+            sp = sbase = 0;
+            ray_boxes = 0u;
+          }
+        }
+        if (go) active = true;
+        else if (kFirst && !wrote) stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
+      }
+    }
+    if (__ballot(active) == 0ull) continue;
+    step();
+  }
+
+  // ---- the end of the launch: no rays left to fetch.  Lanes fall idle one by one; idle lanes take over parts of the
+  // busy lanes' walks (split).  A wavefront runs with few others here, so an iteration costs its dependent round trips:
+  // a retire is two of its own (the winner's parent box and normal, then the stores the next wait sits out) and a split
+  // is a chain of LDS round trips -- measured 1600 + 1600 cycles beside a 2400-cycle step when both ran every iteration
+  // (profiles/r04_tailprof_before_*.txt) -- so finished lanes are retired a few at a time and until then are no takers.
+#ifdef PT_TAILPROF
+  tp_exhausted = wall_clock64();
+  tp_iters_exh = tp_iters;
+  tp_lanes_exh = (uint32_t)__popcll(__ballot(active));
+#endif
+  for (;;) {
+    const uint32_t idle = (uint32_t)__popcll(__ballot(!active));
+#ifdef PT_TAILPROF
+    ++tp_iters;
+#endif
+    if (sc.split_idle != 0u && idle >= sc.split_idle && ++since_split >= PT_SPLIT_EVERY) {
+      since_split = 0u;
+#ifdef PT_TAILPROF
+      const unsigned long long c0 = clock64();
+#endif
+      const uint32_t waiting = (uint32_t)__popcll(__ballot(pending));
+      if (waiting != 0u && (waiting >= PT_RETIRE_LANES || ++since_retire >= PT_RETIRE_EVERY || idle == (uint32_t)kWave)) {
+        since_retire = 0u;
+        if (pending) {
+          retire();
+          pending = false;
+        }
+      }
+#ifdef PT_TAILPROF
+      const unsigned long long c1 = clock64();
+#endif
+      split();
+#ifdef PT_TAILPROF
+      ++tp_splits;
+      tp_c_retire += c1 - c0;
+      tp_c_split += clock64() - c1;
+#endif
+    }
+    if (__ballot(active) == 0ull) {
+      if (pending) {
+        retire();
+        pending = false;
+      }
+      break;
+    }
+#ifdef PT_TAILPROF
+    const unsigned long long c2 = clock64();
+    tp_lanes_tail += (unsigned long long)__popcll(__ballot(active));
+#endif
+    step();
+#ifdef PT_TAILPROF
+    tp_c_step += clock64() - c2;
+#endif
   }
 #ifdef PT_TAILPROF
   if (threadIdx.x == 0u && blockIdx.x < 8192u && bounce < 16) {
@@ -1656,7 +1703,11 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     tp[0] = tp_start;
     tp[1] = tp_exhausted;
     tp[2] = wall_clock64();
-    tp[3] = ((unsigned long long)tp_iters << 32) | tp_splits;
+    tp[3] = ((unsigned long long)tp_iters << 40) | ((unsigned long long)tp_iters_exh << 16) | ((unsigned long long)tp_lanes_exh << 8) | min(tp_splits, 255u);
+    tp[4] = tp_c_retire;
+    tp[5] = tp_c_split;
+    tp[6] = tp_c_step;
+    tp[7] = tp_lanes_tail;
   }
 #endif
   if (flags) atomicOr(&counters->flags, flags);

@@ -46,18 +46,21 @@ def main():
     if args.share_of > 1:
         pt.set_interleave(0, args.share_of, 8)
     pt.max_iterations = 1 << 30
-    for _ in range(args.repeat + 1):
+    lib.ptc_debug_tailprof.restype = C.c_int
+    lib.ptc_debug_tailprof.argtypes = [C.c_void_p, C.c_size_t]
+    for rep in range(args.repeat + 1):
+        if rep == args.repeat:
+            assert lib.ptc_debug_tailprof(None, 0) == 0     # clear: only the last batch is read
         for _ in range(args.frames):
             pt.path_trace(scene.camera)
         pt.synchronize()
-    buf = np.zeros((16, 8192, 4), dtype=np.uint64)
-    lib.ptc_debug_tailprof.restype = C.c_int
-    lib.ptc_debug_tailprof.argtypes = [C.c_void_p, C.c_size_t]
+    buf = np.zeros((16, 8192, 8), dtype=np.uint64)
     assert lib.ptc_debug_tailprof(buf.ctypes.data, buf.nbytes) == 0
     live = pt.stats()["last_live"]
     pt.close()
     print(f"share 1/{args.share_of}, {args.frames} frames per launch; times in us from the first wavefront's start")
-    print("bounce  waves  rays(last frame)  span   first_exh  med_exh  last_exh | exits after first_exh: p50   p90   p99   last | iters mean  max | waves that split")
+    print("bounce  waves  rays(last frame)  span   first_exh  med_exh  last_exh | exits after first_exh: p50   p90   p99   last | iters mean  max | "
+          "own tail (exit - own exhaustion): us p50 p90 max | iterations p50 p90 max | us/iter before, in the tail | lanes busy at exhaustion p50 | waves that split")
     for b in range(MB):
         rec = buf[b]
         ran = rec[:, 2] != 0
@@ -68,13 +71,24 @@ def main():
         start = (r[:, 0] - t0) / 100.0
         exh = np.where(r[:, 1] != 0, (r[:, 1].astype(np.int64) - np.int64(t0)) / 100.0, np.nan)
         end = (r[:, 2] - t0) / 100.0
-        iters = (r[:, 3] >> np.uint64(32)).astype(np.int64)
-        splits = (r[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
+        iters = (r[:, 3] >> np.uint64(40)).astype(np.int64)
+        iters_exh = ((r[:, 3] >> np.uint64(16)) & np.uint64(0xffffff)).astype(np.int64)
+        lanes_exh = ((r[:, 3] >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
+        splits = (r[:, 3] & np.uint64(0xff)).astype(np.int64)
+        own = end - exh
+        tail_it = iters - iters_exh
+        ok = ~np.isnan(exh)
         fe = np.nanmin(exh)
         after = end - fe
         print(f"{b:5d} {ran.sum():6d} {live[b]:12d}   {end.max():7.1f} {fe:9.1f} {np.nanmedian(exh):8.1f} {np.nanmax(exh):8.1f} |"
               f" {np.percentile(after, 50):21.1f} {np.percentile(after, 90):5.1f} {np.percentile(after, 99):5.1f} {after.max():6.1f} |"
-              f" {iters.mean():8.1f} {iters.max():5d} | {(splits > 0).sum():6d}   late starts (>5us): {(start > 5).sum()}")
+              f" {iters.mean():8.1f} {iters.max():5d} | {np.nanpercentile(own, 50):6.1f} {np.nanpercentile(own, 90):6.1f} {np.nanmax(own):6.1f} |"
+              f" {np.percentile(tail_it[ok], 50):5.0f} {np.percentile(tail_it[ok], 90):5.0f} {tail_it[ok].max():5d} |"
+              f" {np.nansum(exh - start) / max(iters_exh[ok].sum(), 1):5.2f} {np.nansum(own) / max(tail_it[ok].sum(), 1):5.2f} |"
+              f" {np.percentile(lanes_exh[ok], 50):3.0f} | {(splits > 0).sum():6d}   late starts (>5us): {(start > 5).sum()}")
+        ti = max(int(tail_it[ok].sum()), 1)
+        print(f"        shader-clock cycles per tail iteration: retire {r[ok, 4].sum() / ti:7.0f}  split {r[ok, 5].sum() / ti:7.0f}  step {r[ok, 6].sum() / ti:7.0f}"
+              f"   active lanes per tail iteration {r[ok, 7].sum() / ti:5.1f}")
 
 
 if __name__ == "__main__":
