@@ -1234,13 +1234,6 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     }
     ++sp;
   };
-  // the top entry without removing it (kNoChild for an empty stack)
-  auto peek = [&]() -> uint32_t {
-    const int top = sp - 1;
-    uint32_t r = stack[min(max(top, 0), lds_cap - 1) * kWave];
-    if (__builtin_expect(top >= lds_cap, 0)) r = sc.spill[(size_t)(top - lds_cap) * sc.spill_stride + gid].x;
-    return top >= sbase ? r : kNoChild;
-  };
   // the conservative slab pair of one box for this lane's ray, tolerance folded INWARDS: if even that interval is
   // non-empty, the reference's exact test of the box passes
   auto surely_inside = [&](const f3 lo, const f3 hi) -> bool {
@@ -1405,32 +1398,36 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       const bool is_leaf = (cur & kLeafBit) != 0u;
       const uint32_t index = cur & ~kLeafBit;
       // The four loads are written as instructions: left to the compiler they are split by use (the leaf branch
-      // needs 36 of the 64 bytes), narrowed and partly sunk into the branches -- five to seven loads again.  The
-      // compiler does not count these in its s_waitcnt bookkeeping, so the wait is explicit and carries the four
-      // results as operands: nothing can read them before it.  (Loads return in order, so the compiler's own
-      // vmcnt waits elsewhere stay conservative.)
+      // needs 36 of the 64 bytes), narrowed and partly sunk into the branches -- five to seven loads again.
+      // Loads, the LDS read of the stack entry the lane falls back to, and the ONE wait for all of them are a single asm
+      // statement (round 4).  Until then the loads and the wait were separate statements around compiler-issued code:
+      // the compiler believes a hand-issued load complete the moment it is issued and is free to spill or move a
+      // destination register in between (nothing it does shows up in its wait bookkeeping either: a build of round 2
+      // waited between the loads, -17 %).  As one statement there is no "in between"; early-clobber outputs keep the
+      // addresses alive until the last load is out.
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       u32x4 w0, w1, w2, w3;
-      // The compiler's own wait bookkeeping does not see the explicit waits of earlier iterations either: a load it
-      // issued itself long ago (ray fetch, finalize) can still count as "in flight" on some path into this block,
-      // and the wait it then inserts in front of the first instruction that touches the register lands wherever
-      // register allocation puts that register -- between the four loads below in two measured builds (each load
-      // then waits for the one before: 17 % slower).  A wait it does understand, here, where nothing is in flight,
-      // clears its books for the whole group.
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       // (the "fourth quarter" of a 48-byte triangle record would be the head of the next record: its last 16 bytes
       // are requested twice instead; a 64-byte record is simply read whole)
       constexpr bool kLeaf48 = kTriVec4 == 3u;
       const char* rec = is_leaf ? reinterpret_cast<const char*>(tris) + (16u * kTriVec4) * (size_t)index
                                 : reinterpret_cast<const char*>(sc.cur.bvh4q) + 64u * (size_t)index;
       const char* rec3 = rec + (kLeaf48 && is_leaf ? 32 : 48);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w0) : "v"(rec));
-      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(w1) : "v"(rec));
-      asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(w2) : "v"(rec));
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w3) : "v"(rec3));
-      const uint32_t below = peek();
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the four loads have landed (a wait the compiler's bookkeeping sees)
-      asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));  // ... and nothing reads them above this line
+      const int top = sp - 1;  // (peek(): the top entry without removing it)
+      const uint32_t below_addr = (uint32_t)(uintptr_t)(stack + min(max(top, 0), lds_cap - 1) * kWave);
+      uint32_t below;
+      asm volatile(
+          "global_load_dwordx4 %0, %5, off\n\t"
+          "global_load_dwordx4 %1, %5, off offset:16\n\t"
+          "global_load_dwordx4 %2, %5, off offset:32\n\t"
+          "global_load_dwordx4 %3, %6, off\n\t"
+          "ds_read_b32 %4, %7\n\t"
+          "s_waitcnt vmcnt(0) lgkmcnt(0)"
+          : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(below)
+          : "v"(rec), "v"(rec3), "v"(below_addr)
+          : "memory");
+      if (__builtin_expect(top >= lds_cap, 0)) below = sc.spill[(size_t)(top - lds_cap) * sc.spill_stride + gid].x;
+      below = top >= sbase ? below : kNoChild;
       const uint4 q0 = make_uint4(w0.x, w0.y, w0.z, w0.w), q1 = make_uint4(w1.x, w1.y, w1.z, w1.w);
       const uint4 q2 = make_uint4(w2.x, w2.y, w2.z, w2.w), q3 = make_uint4(w3.x, w3.y, w3.z, w3.w);
       if (!is_leaf) {

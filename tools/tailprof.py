@@ -88,7 +88,9 @@ def main():
               f" {np.percentile(lanes_exh[ok], 50):3.0f} | {(splits > 0).sum():6d}   late starts (>5us): {(start > 5).sum()}")
         ti = max(int(tail_it[ok].sum()), 1)
         print(f"        shader-clock cycles per tail iteration: retire {r[ok, 4].sum() / ti:7.0f}  split {r[ok, 5].sum() / ti:7.0f}  step {r[ok, 6].sum() / ti:7.0f}"
-              f"   active lanes per tail iteration {r[ok, 7].sum() / ti:5.1f}")
+              f"   active lanes per tail iteration {(r[ok, 7] & np.uint64(0xffffff)).sum() / ti:5.1f}"
+              f"   rays handed over: given {int(((r[:, 7] >> np.uint64(24)) & np.uint64(0xfff)).sum())} taken {int(((r[:, 7] >> np.uint64(36)) & np.uint64(0xfff)).sum())}"
+              f" by {int((((r[:, 7] >> np.uint64(36)) & np.uint64(0xfff)) > 0).sum())} wavefronts")
 
 
 if __name__ == "__main__":
