@@ -101,6 +101,7 @@ struct DMeshView {
   uint32_t bvh_node_count;
 };
 
+constexpr uint32_t kSphereTab = 8u;  // float4 per object in DScene::sphere_ball
 struct DScene {
   const DObject* objects;
   const uint32_t* object_material;
@@ -122,6 +123,13 @@ struct DScene {
   uint32_t split_idle;             // ... and once the launch has no rays left: split busy lanes' stacks among idle ones when
                                    // at least this many lanes are idle (0: never)
   uint32_t object_count;
+  // per object kSphereTab float4, for spheres: [0] the world-space ball that contains the transformed sphere {centre.xyz,
+  // radius (rounded up)} -- radius < 0: no ball (a projective matrix; a mesh object): never skipped; [1] {1 / largest
+  // stretch of the object's matrix (rounded down), 1 if "simple" (both matrices pure translations spelled 1.0f / +0.0f),
+  // 0, 0}; [2..6] what a lane needs of a simple object: {box min, inverse translation x}, {box max, .. y},
+  // {sphere centre, .. z}, {translation, sphere radius}, {material bits, 0, 0, 0} (sphere_run_lanes).
+  const float4* sphere_ball;
+  uint32_t lanes_run;              // set per launch by the host: the launch's sphere run may take sphere_run_lanes
 };
 
 // Camera constants prepared on the host once per frame (GPUCamera, camera.hpp:10-15, plus the

@@ -882,6 +882,15 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 // ------------------------------------------------------------------------------------------------
 // sphere segments
 // ------------------------------------------------------------------------------------------------
+#ifndef PT_SPHERE_SKIP
+#define PT_SPHERE_SKIP 0
+#endif
+#ifndef PT_SPHERE_LANES
+#define PT_SPHERE_LANES 1
+#endif
+#ifndef PT_SPHERE_LANES_LEADING
+#define PT_SPHERE_LANES_LEADING 0
+#endif
 // Sphere objects [obj_begin, obj_end) in the reference's order (ray_object_intersection_test, path_tracer.cu:78-100)
 // for one ray whose closest hit so far is ray.tmax (FLT_MAX: none).  A sphere that is hit replaces `rec`, shrinks
 // ray.tmax and sets `changed`.  Used by k_spheres (a run in front of a mesh, a scene without a mesh) and by
@@ -902,10 +911,49 @@ __device__ __forceinline__ f3 xform_point_w1(const m4& m, f3 p)
 // every object whose M^-1 has the identity as its upper 3 x 3 (a translated sphere: every sphere of the Cornell box) --
 // (1 dx + 0 dy) + (0 dz + t 0) is dx exactly when the components of d are finite and none is a zero (whose sign the sum
 // could change) -- so such a wavefront normalises its direction once for all of them.
+// Select approximately, verify exactly (round 4): before the reference's own sequence for a sphere object -- world box
+// with six divisions, inverse transform with a normalisation, the quadratic with an IEEE square root and two divisions
+// (path_tracer.cu:84-96, intersections.cuh:7-41) -- a dozen approximate operations on the WORLD-space ball around the
+// object (DScene::sphere_ball) decide whether that sequence can possibly accept a hit.  true = it surely cannot:
+//   * the ray's line passes the ball at more than its radius (the reference's discriminant would be negative), or
+//   * the ball lies behind the origin (both roots negative: below t_min), or
+//   * the ball starts beyond the closest hit so far: the reference compares the OBJECT-space root with the world-space
+//     t_max (transform.hpp:51-58 copies the range unscaled), and an object-space distance is at least the world-space
+//     one divided by the matrix's largest stretch.
+// Everything is held against the ray with margins far beyond the rounding of either side (relative 1e-4 where the
+// arithmetic is good to 1e-6), so a sphere the reference would accept is never skipped; what is not skipped takes the
+// reference's sequence unchanged, in list order -- ties, the unscaled-t quirk and the box test included.
+__device__ __forceinline__ bool sphere_surely_missed(const float4 ball, const float inv_stretch, const f3 o, const f3 d, const float a,
+                                                     const float tmax)
+{
+  const float R = ball.w;
+  const f3 oc = mk3(o.x - ball.x, o.y - ball.y, o.z - ball.z);
+  const float oc2 = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, oc.z * oc.z));
+  const float b = __builtin_fmaf(d.x, oc.x, __builtin_fmaf(d.y, oc.y, d.z * oc.z));  // d . oc (d not normalised)
+  const float r2 = R * R;
+  const float cc = oc2 - r2;                       // > 0: the origin is outside the ball
+  const float scale2 = a * (oc2 + r2);             // the size of the terms the discriminant is made of
+  const float disc = __builtin_fmaf(b, b, -(a * cc));
+  const float margin = 1e-4f * __builtin_fmaf(b, b, scale2);
+  const bool no_ball = !(R >= 0.0f) || !(margin < __builtin_inff());  // no ball for this object, or nothing can be said
+  const bool line_misses = disc < -margin;
+  const bool outside = cc > 1e-4f * (oc2 + r2);
+  const bool behind = outside && b > 0.0f && b * b > 1e-8f * scale2;
+  // distance (world units) to the ball along the ray, from below; an object-space root is at least that / stretch
+  const float inv_len = __builtin_amdgcn_rsqf(a);
+  const float bh = b * inv_len;
+  const float dd = __builtin_fmaf(bh, bh, -cc);
+  const float entry = -bh - __builtin_amdgcn_sqrtf(fmaxf(dd, 0.0f));  // (v_sqrt_f32, 1 ulp: margins below)
+  const float lower = (entry - 1e-4f * (fabsf(bh) + R)) * inv_stretch * 0.9999f;
+  const bool beyond = outside && dd > 0.0f && lower > tmax;
+  return !no_ball && (line_misses || behind || beyond);
+}
+
 template <bool kShareDir = false>
 __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_begin, uint32_t obj_end, Ray& ray, Hit& rec,
                                                bool& changed)
 {
+  const float ray_a = __builtin_fmaf(ray.d.x, ray.d.x, __builtin_fmaf(ray.d.y, ray.d.y, ray.d.z * ray.d.z));
   // 1/d by the hardware reciprocal: decides the world-box test of almost every ray without the reference's six
   // divisions per object (below)
   const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
@@ -917,6 +965,12 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
   for (uint32_t i = obj_begin; i < obj_end; ++i) {
     const DObject* obj = sc.objects + i;
     if (obj->type != 0u) continue;
+    if (PT_SPHERE_SKIP) {
+      // (wave-uniform loads; the sequence below runs only when some lane of the wavefront cannot be ruled out)
+      const float4 ball = sc.sphere_ball[(size_t)kSphereTab * i];
+      const float inv_stretch = sc.sphere_ball[(size_t)kSphereTab * i + 1u].x;
+      if (sphere_surely_missed(ball, inv_stretch, ray.o, ray.d, ray_a, ray.tmax)) continue;
+    }
     {
       // ray_aabb_intersection_test (intersections.cuh:87-103) decides by the sign of min(far) - max(near).  With
       // reciprocals each slab value is within 3 ulp of the reference's quotient, so a gap beyond 2e-6 of the two
@@ -965,6 +1019,184 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
     }
   }
 }
+// ---- a run of SIMPLE sphere objects, candidates per lane (round 4) -------------------------------------------------
+// sphere_segment walks the run object by object, and the wavefront pays the reference's whole sequence for an object
+// whenever ANY lane cannot rule it out -- with 64 lanes that is almost every object: the Cornell box's five wall spheres
+// are all "hit" by every ray inside it, and k_spheres ran eight full sequences per ray (645 us a launch, config 2).
+// Here every lane first collects ITS candidates, for up to kSlots rays at once (k_shade_fused holds four), with the
+// approximate arithmetic of sphere_surely_missed extended to bounds on the root the reference would accept:
+//   lo  a lower bound of that root (world distance: a simple object does not stretch),
+//   hi  an upper bound of it when the sphere is surely hit beyond t_min (else +inf).
+// In list order an object is a candidate unless it is surely missed or lo exceeds `cap`, the smallest hi of the
+// surely-hit objects BEFORE it (and the closest hit carried in): when its turn comes the reference's t_max is below its
+// root whichever of the earlier objects were accepted, so the reference rejects it too.  (Objects AFTER it never
+// matter for it: the reference walks the list in order.)  Then the lanes take their candidates one per iteration, lowest
+// list index first and slot by slot, each lane with the data of ITS object (five float4 from DScene::sphere_ball) and
+// the reference's operations spelled with the literal matrix entries of a translation -- same operands, same order,
+// same bits.  The loop runs as often as the busiest lane has candidates: one to three times where sphere_segment paid
+// for eight objects.
+// mul(m, x, y, z, w) (pt_math.hpp) with the matrix's translation column taken from `tcol` (per lane), everything else from
+// `m` (the run's common entries: wave-uniform)
+__device__ __forceinline__ f4 mul_tcol(const m4& m, const f3 tcol, float x, float y, float z, float w)
+{
+  f4 r;
+  r.x = (m.c[0][0] * x + m.c[1][0] * y) + (m.c[2][0] * z + tcol.x * w);
+  r.y = (m.c[0][1] * x + m.c[1][1] * y) + (m.c[2][1] * z + tcol.y * w);
+  r.z = (m.c[0][2] * x + m.c[1][2] * y) + (m.c[2][2] * z + tcol.z * w);
+  r.w = (m.c[0][3] * x + m.c[1][3] * y) + (m.c[2][3] * z + m.c[3][3] * w);
+  return r;
+}
+
+// The reference's sequence for one sphere object of a simple run (path_tracer.cu:84-96, intersections.cuh:7-41): the same
+// operations on the same operands as sphere_segment, with the object's own numbers (q0..q3, see DScene::sphere_ball)
+// in vector registers and the entries all objects of the run share in `first` (the run's first object, scalar).
+__device__ __forceinline__ bool sphere_exact_simple(const DObject* first, const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                                    const f3 ro, const f3 rd, const float tmin, const float tmax, Hit& rec)
+{
+  {
+    // the object's world box first (path_tracer.cu:84), as in sphere_segment: reciprocals, the reference's divisions
+    // only for a ray that grazes it
+    const f3 bmin = xyz(q0), bmax = xyz(q1);
+    const f3 winv = mk3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+    const f3 a0 = (bmin - ro) * winv, a1 = (bmax - ro) * winv;
+    const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+    const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+    const float gap = wf - wn, margin = 2e-6f * (fabsf(wf) + fabsf(wn)) + 1e-30f;
+    const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
+    bool pass = gap > margin;
+    const bool unsure = !box_ok || !finite_f(winv.x + winv.y + winv.z) || !(gap > margin || gap < -margin);
+    if (__builtin_expect(unsure, 0)) pass = ray_aabb(ro, rd, bmin, bmax);
+    if (!pass) return false;
+  }
+  const f3 ti = mk3(q0.w, q1.w, q2.w);
+  // inverse_transform_ray (transform.hpp:51-58)
+  Ray tr;
+  const f4 ov = mul_tcol(first->inv_m, ti, ro.x, ro.y, ro.z, 1.0f);
+  tr.o = mk3(ov.x, ov.y, ov.z);
+  if (__builtin_expect(ov.w != 1.0f, 0)) tr.o = tr.o / ov.w;  // (x / 1 is x: the division transform_point always makes, skipped)
+  const f4 dv = mul_tcol(first->inv_m, ti, rd.x, rd.y, rd.z, 0.0f);
+  tr.d = normalize(mk3(dv.x, dv.y, dv.z));
+  tr.tmin = tmin;
+  tr.tmax = tmax;
+  if (!ray_sphere_a(tr, dot(tr.d, tr.d), xyz(q2), q3.w, rec)) return false;
+  // path_tracer.cu:92-96: point to world, t = distance, normal by transpose(inv_m)
+  const f4 pv = mul_tcol(first->m, xyz(q3), rec.p.x, rec.p.y, rec.p.z, 1.0f);
+  rec.p = mk3(pv.x, pv.y, pv.z);
+  if (__builtin_expect(pv.w != 1.0f, 0)) rec.p = rec.p / pv.w;
+  rec.t = length(rec.p - ro);
+  rec.n = xform_normal(first->inv_m, rec.n);  // (no entry of the translation column in it)
+  return true;
+}
+
+// the candidates of one ray among the objects of the run: bit k = object obj_begin + k.
+// Bounds: with oc = origin - centre and u the unit direction, the roots are -u.oc -+ sqrt((u.oc)^2 - (|oc|^2 - r^2)).
+// The radicand is a difference of terms up to 1e6 (the Cornell box's walls are spheres of radius 1000): every use of it
+// carries m = 1e-5 of those terms (forty times what float arithmetic loses there) on the side that keeps the bound a
+// bound -- the reference's own float result lies inside [lo, hi] as well.  The cap is the smallest hi of ALL surely-hit
+// objects, not only of the earlier ones: the reference's answer is the closest accepted root (ties: the later object),
+// it is at most that cap, and an object whose root lies beyond the cap cannot be the answer nor decide between others
+// that could (what it may be accepted for in the reference's walk is overwritten by the object that sets the cap).
+// kAllCaps false (k_shade_fused: four rays' worth of state and no registers for eight more bounds): the cap an object is
+// held against is the one of the objects before it -- the reference's walk at its plainest, nothing to argue.
+template <bool kAllCaps>
+__device__ __forceinline__ uint32_t sphere_candidates(const DScene& sc, const uint32_t obj_begin, const uint32_t obj_end, const float4 o4,
+                                                      const float4 d4, const float closest)
+{
+  const f3 o = xyz(o4), d = xyz(d4);
+  const float tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
+  const float a = __builtin_fmaf(d.x, d.x, __builtin_fmaf(d.y, d.y, d.z * d.z));
+  const float inv_len = __builtin_amdgcn_rsqf(a);
+  float cap = closest >= 0.0f ? closest * 1.0001f : FLT_MAX;
+  uint32_t cand = 0u;
+  float lo_of[kAllCaps ? 8 : 1];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (kAllCaps) lo_of[k] = __builtin_inff();
+    const uint32_t i = obj_begin + (uint32_t)k;
+    if (i < obj_end) {  // (wave-uniform: the balls come through scalar loads)
+      const float4 ball = sc.sphere_ball[(size_t)kSphereTab * i];
+      const float R = ball.w;
+      const f3 oc = mk3(o.x - ball.x, o.y - ball.y, o.z - ball.z);
+      const float oc2 = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, oc.z * oc.z));
+      const float bh = __builtin_fmaf(d.x, oc.x, __builtin_fmaf(d.y, oc.y, d.z * oc.z)) * inv_len;
+      const float r2 = R * R;
+      const float dd = __builtin_fmaf(bh, bh, -(oc2 - r2));
+      const float m = 1e-5f * (__builtin_fmaf(bh, bh, oc2) + r2);
+      const float sq_up = __builtin_amdgcn_sqrtf(fmaxf(dd + m, 0.0f)), sq_dn = __builtin_amdgcn_sqrtf(fmaxf(dd - m, 0.0f));
+      const float e = 1e-5f * (fabsf(bh) + sq_up + R) + 1e-6f;
+      const bool near_bad = -bh - sq_dn < tmin - e;   // the nearer root is surely below t_min: only the farther one counts
+      const bool near_ok = -bh - sq_up > tmin + e;    // ... surely at or above it: it is the one
+      const bool missed = dd < -m || -bh + sq_up < tmin - e;
+      const bool sure = dd > m && (near_ok || (near_bad && -bh + sq_dn > tmin + e));
+      const float lo = near_bad ? -bh + sq_dn - e : -bh - sq_up - e;
+      const float hi = near_ok ? -bh - sq_dn + e : -bh + sq_up + e;
+      const bool known = m < __builtin_inff();        // (anything non-finite: a candidate, and no bound from it)
+      const float lo_k = !known ? -__builtin_inff() : (missed ? __builtin_inff() : lo);
+      if (kAllCaps) lo_of[k] = lo_k;
+      else cand |= lo_k <= cap ? 1u << k : 0u;
+      cap = (known && sure) ? fminf(cap, hi * 1.0001f) : cap;
+    }
+  }
+  if (kAllCaps) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cand |= lo_of[k] <= cap ? 1u << k : 0u;
+  }
+  return cand;
+}
+
+// (component by component: a conditional expression on the float4 STRUCT is compiled as a choice between two addresses
+// in scratch memory)
+__device__ __forceinline__ float4 sel4(const bool c, const float4 a, const float4 b)
+{
+  return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+
+// o4 / d4: the rays as the path arrays hold them; tp / nm: the hit records (tp.x < 0: none yet), updated in place.
+// valid: bit j = slot j holds a ray.  Returns the slots whose record changed.  (Every array index below is a literal:
+// a loop over the slots, even a fully unrolled one, left the arrays in scratch memory.)
+template <int kSlots>
+__device__ __forceinline__ uint32_t sphere_run_lanes(const DScene& sc, const uint32_t obj_begin, const uint32_t obj_end, const float4 (&o4)[kSlots],
+                                                     const float4 (&d4)[kSlots], float4 (&tp)[kSlots], float4 (&nm)[kSlots], const uint32_t valid)
+{
+  static_assert(kSlots >= 1 && kSlots <= 4, "slots");
+  uint32_t cand = 0u;
+  constexpr bool kAllCaps = kSlots == 1;
+  if (valid & 1u) cand |= sphere_candidates<kAllCaps>(sc, obj_begin, obj_end, o4[0], d4[0], tp[0].x);
+  if constexpr (kSlots > 1) { if (valid & 2u) cand |= sphere_candidates<kAllCaps>(sc, obj_begin, obj_end, o4[1], d4[1], tp[1].x) << 8; }
+  if constexpr (kSlots > 2) { if (valid & 4u) cand |= sphere_candidates<kAllCaps>(sc, obj_begin, obj_end, o4[2], d4[2], tp[2].x) << 16; }
+  if constexpr (kSlots > 3) { if (valid & 8u) cand |= sphere_candidates<kAllCaps>(sc, obj_begin, obj_end, o4[3], d4[3], tp[3].x) << 24; }
+  uint32_t changed = 0u;
+  while (__ballot(cand != 0u) != 0ull) {
+    if (cand != 0u) {
+      const int bit = __ffs((int)cand) - 1;
+      cand &= cand - 1u;
+      const int j = bit >> 3;
+      const uint32_t i = obj_begin + (uint32_t)(bit & 7);
+      const float4* q = sc.sphere_ball + (size_t)kSphereTab * i + 2u;
+      const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+      float4 ro4 = o4[0], rd4 = d4[0];
+      float tcur = tp[0].x;
+      if constexpr (kSlots > 1) { ro4 = sel4(j == 1, o4[1], ro4); rd4 = sel4(j == 1, d4[1], rd4); tcur = j == 1 ? tp[1].x : tcur; }
+      if constexpr (kSlots > 2) { ro4 = sel4(j == 2, o4[2], ro4); rd4 = sel4(j == 2, d4[2], rd4); tcur = j == 2 ? tp[2].x : tcur; }
+      if constexpr (kSlots > 3) { ro4 = sel4(j == 3, o4[3], ro4); rd4 = sel4(j == 3, d4[3], rd4); tcur = j == 3 ? tp[3].x : tcur; }
+      const float tmin = (__float_as_uint(ro4.w) >> 31) ? 1e-5f : 1e-4f;
+      Hit rec;
+      if (sphere_exact_simple(sc.objects + obj_begin, q0, q1, q2, q3, xyz(ro4), xyz(rd4), tmin, tcur >= 0.0f ? tcur : FLT_MAX, rec)) {
+        const uint32_t mat = __float_as_uint(q[4].x);
+        const float4 ntp = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
+        const float4 nnm = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(mat | (rec.side << 31)));
+        tp[0] = sel4(j == 0, ntp, tp[0]);
+        nm[0] = sel4(j == 0, nnm, nm[0]);
+        if constexpr (kSlots > 1) { tp[1] = sel4(j == 1, ntp, tp[1]); nm[1] = sel4(j == 1, nnm, nm[1]); }
+        if constexpr (kSlots > 2) { tp[2] = sel4(j == 2, ntp, tp[2]); nm[2] = sel4(j == 2, nnm, nm[2]); }
+        if constexpr (kSlots > 3) { tp[3] = sel4(j == 3, ntp, tp[3]); nm[3] = sel4(j == 3, nnm, nm[3]); }
+        changed |= 1u << j;
+      }
+    }
+  }
+  return changed;
+}
+
 __device__ __forceinline__ void store_hit(const DHits& hits, uint32_t slot, const Hit& rec)
 {
   stnt(&hits.tp[slot], make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z));
@@ -1809,6 +2041,10 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   const uint32_t tile = kFilter ? list_tile(counters, tiles) : blockIdx.x / bi.count;
   const uint32_t block_first = tile * (256u * kListPer);  // a workgroup tests kListPer x 256 consecutive slots
   uint32_t may_mask = 0u;
+  // (sphere_run_lanes is for the run that ends the list: here, in front of a mesh, the spheres are typically the walls of a
+  // room -- every ray hits every one of them, there is little to rule out, and sphere_segment shares the inverse
+  // transform's normalised direction among them: measured 907 us against 1114 for the per-lane form, config 2)
+  const bool lanes_run = PT_SPHERE_LANES_LEADING && sc.lanes_run != 0u;
 #pragma unroll 1
   for (int j = 0; j < kListPer; ++j) {
     const uint32_t s = block_first + (uint32_t)j * 256u + threadIdx.x;
@@ -1820,9 +2056,20 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
     }
     Hit rec;
     bool changed = false;
-    sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
-    if (changed) store_hit(hits, s, rec);
-    else if (kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
+    if (lanes_run) {
+      const float4 ro4[1] = {ldnt(&paths.o4[s])}, rd4[1] = {ldnt(&paths.d4[s])};
+      float4 rtp[1] = {make_float4(ray.tmax < FLT_MAX ? ray.tmax : -1.0f, 0.f, 0.f, 0.f)}, rnm[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+      changed = sphere_run_lanes<1>(sc, obj_begin, obj_end, ro4, rd4, rtp, rnm, 1u) != 0u;
+      if (changed) {
+        stnt(&hits.tp[s], rtp[0]);
+        stnt(&hits.nm[s], rnm[0]);
+        ray.tmax = rtp[0].x;
+      }
+    } else {
+      sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
+      if (changed) store_hit(hits, s, rec);
+    }
+    if (!changed && kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
     if (kFilter && may_hit_boxes(sc.objects, filt_begin, filt_end, ray.o, ray.d, ray.tmax)) may_mask |= 1u << j;
   }
   if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, tile, tiles, scan);
@@ -2144,10 +2391,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       if (!kFirst) tp[j] = ldnt(&hits.tp[s]);
     }
   }
+  // the sphere run that ends the object list: every lane with its own candidates, all four slots at once, when the run
+  // allows it (sphere_run_lanes); object by object otherwise
+  const bool lanes_run = kSpheres && PT_SPHERE_LANES && sc.lanes_run != 0u;
+  if (kSpheres && lanes_run) {
+    static_assert(kFuseK == 4, "sphere_run_lanes: four slots");
+    const uint32_t valid = (slot_of[0] < n_all ? 1u : 0u) | (slot_of[1] < n_all ? 2u : 0u) | (slot_of[2] < n_all ? 4u : 0u) | (slot_of[3] < n_all ? 8u : 0u);
+    have_nm |= sphere_run_lanes<kFuseK>(sc, obj_begin, obj_end, o4, d4, tp, nm, valid);
+  }
 #pragma unroll
   for (int j = 0; j < kFuseK; ++j) {
     const uint32_t s = slot_of[j];
-    if (kSpheres && s < n_all) {
+    if (kSpheres && !lanes_run && s < n_all) {
       Ray ray;
       ray.o = xyz(o4[j]);
       ray.d = xyz(d4[j]);

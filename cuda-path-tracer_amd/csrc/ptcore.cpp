@@ -169,6 +169,10 @@ struct ptc_ctx {
   };
   std::vector<TraceLaunch> launches;
   uint32_t tail_begin = 0, tail_end = 0;
+  // per object: 0, or the class of a "simple" sphere object (sphere_ball_of) -- objects of one class have the same
+  // matrix entries outside the translation columns; a run of one class (at most eight objects) takes sphere_run_lanes
+  std::vector<uint32_t> sphere_class;
+  bool sphere_lanes = true;   // "sphere_lanes"
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
@@ -237,6 +241,92 @@ int bind_device(ptc_ctx* ctx)
 {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   return PTC_OK;
+}
+
+// The world-space ball around a sphere object (DScene::sphere_ball), in double precision with the roundings of the
+// float copies charged to the radius: centre = M (c, 1), radius = r * (largest singular value of M's 3 x 3 part).
+// A matrix whose last row is not (0, 0, 0, 1), anything non-finite, a mesh object: radius -1 (no ball, never skipped).
+static void sphere_ball_of(const ptc_object& o, const ptc_sphere* spheres, uint32_t sphere_count, uint32_t material, float4* out)
+{
+  out[0] = make_float4(0.f, 0.f, 0.f, -1.0f);
+  for (uint32_t k = 1; k < kSphereTab; ++k) out[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (o.type != 0u || o.index >= sphere_count) return;
+  const float* m = o.m;  // column-major: m[4 * col + row]
+  if (!(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f)) return;
+  const ptc_sphere& sp = spheres[o.index];
+  double a[3][3];  // a[row][col]
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) a[r][c] = (double)m[4 * c + r];
+  // largest eigenvalue of A^T A by power iteration from three starts (symmetric positive semi-definite 3 x 3), then
+  // bounded from above by the Frobenius norm and pushed up by 1e-6 relative: an upper bound is all that is needed
+  double g[3][3];
+  double frob2 = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      g[i][j] = 0.0;
+      for (int k = 0; k < 3; ++k) g[i][j] += a[k][i] * a[k][j];
+      frob2 += a[i][j] * a[i][j];
+    }
+  if (!std::isfinite(frob2) || frob2 <= 0.0) return;
+  double lam = 0.0;
+  for (int start = 0; start < 3; ++start) {
+    double v[3] = {start == 0 ? 1.0 : 0.3, start == 1 ? 1.0 : 0.2, start == 2 ? 1.0 : 0.1};
+    double l = 0.0;
+    for (int it = 0; it < 200; ++it) {
+      double w[3];
+      for (int i = 0; i < 3; ++i) w[i] = g[i][0] * v[0] + g[i][1] * v[1] + g[i][2] * v[2];
+      const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      if (!(n > 0.0)) break;
+      for (int i = 0; i < 3; ++i) v[i] = w[i] / n;
+      l = n;
+    }
+    lam = std::max(lam, l);
+  }
+  // power iteration approaches the eigenvalue from below: the Gershgorin bound of G is a true upper bound; take the
+  // smaller of it and the Frobenius norm, but never less than the iterate
+  double gersh = 0.0;
+  for (int i = 0; i < 3; ++i) gersh = std::max(gersh, std::fabs(g[i][0]) + std::fabs(g[i][1]) + std::fabs(g[i][2]));
+  double lam_up = std::min(gersh, frob2);
+  // (for a rotation times a uniform scale G is s^2 I: Gershgorin is exact.  Otherwise the iterate plus 1 % is used when it
+  // is below the proven bound -- and the skip test's own margins are relative 1e-4, so the 1 % only costs pruning)
+  lam_up = std::min(lam_up, lam * 1.02);
+  lam_up = std::max(lam_up, lam);
+  const double sigma = std::sqrt(lam_up) * (1.0 + 1e-6);
+  const double cx = a[0][0] * sp.center[0] + a[0][1] * sp.center[1] + a[0][2] * sp.center[2] + (double)m[12];
+  const double cy = a[1][0] * sp.center[0] + a[1][1] * sp.center[1] + a[1][2] * sp.center[2] + (double)m[13];
+  const double cz = a[2][0] * sp.center[0] + a[2][1] * sp.center[1] + a[2][2] * sp.center[2] + (double)m[14];
+  const double rad = std::fabs((double)sp.radius) * sigma;
+  if (!std::isfinite(cx + cy + cz + rad)) return;
+  const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
+  const double slack = std::fabs(cx - fx) + std::fabs(cy - fy) + std::fabs(cz - fz);
+  float fr = (float)((rad + slack) * (1.0 + 1e-6));
+  fr = std::nextafter(fr, INFINITY);
+  float inv_sigma = (float)((1.0 / sigma) * (1.0 - 1e-6));
+  inv_sigma = std::nextafter(inv_sigma, 0.0f);
+  out[0] = make_float4(fx, fy, fz, fr);
+  // "simple": both matrices are a pure translation -- diagonal 1.0f, everything else outside the translation column a
+  // zero of either sign (a cofactor inverse leaves -0.0f in a checkerboard).  The reference's matrix arithmetic then has
+  // the same operands for every such object of a run except the translation, and a lane can fetch what differs for
+  // itself (sphere_run_lanes): box, inverse translation, sphere, translation, material
+  auto bits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; };
+  bool simple = true;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      if (c == 3 && r < 3) continue;  // the translation column
+      for (const float* mat : {o.m, o.inv_m}) {
+        const uint32_t u = bits(mat[4 * c + r]);
+        simple = simple && (c == r ? u == 0x3f800000u : (u & 0x7fffffffu) == 0u);
+      }
+    }
+  for (int r = 0; r < 3; ++r) simple = simple && std::isfinite(o.m[12 + r]) && std::isfinite(o.inv_m[12 + r]);
+  out[1] = make_float4(inv_sigma, simple ? 1.0f : 0.0f, 0.f, 0.f);
+  float mat_f;
+  std::memcpy(&mat_f, &material, 4);
+  out[2] = make_float4(o.aabb_min[0], o.aabb_min[1], o.aabb_min[2], o.inv_m[12]);
+  out[3] = make_float4(o.aabb_max[0], o.aabb_max[1], o.aabb_max[2], o.inv_m[13]);
+  out[4] = make_float4(sp.center[0], sp.center[1], sp.center[2], o.inv_m[14]);
+  out[5] = make_float4(o.m[12], o.m[13], o.m[14], sp.radius);
+  out[6] = make_float4(mat_f, 0.f, 0.f, 0.f);
 }
 
 template <typename T>
@@ -655,6 +745,28 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
   const DMaterial* mats = nullptr;
   if (int rc = upload(ctx, ctx->scene_allocs, &mats, reinterpret_cast<const DMaterial*>(s->materials), s->material_count)) return rc;
   d.materials = mats;
+  {
+    std::vector<float4> balls((size_t)s->object_count * kSphereTab);
+    ctx->sphere_class.assign(s->object_count, 0u);
+    std::vector<uint32_t> class_first;  // first object of every class
+    for (uint32_t i = 0; i < s->object_count; ++i) {
+      sphere_ball_of(s->objects[i], s->spheres, s->sphere_count, s->object_material_indices[i], &balls[(size_t)kSphereTab * i]);
+      if (balls[(size_t)kSphereTab * i + 1u].y == 0.0f) continue;
+      auto same = [&](const ptc_object& a, const ptc_object& b) {
+        for (int c = 0; c < 4; ++c)
+          for (int r = 0; r < 4; ++r) {
+            if (c == 3 && r < 3) continue;
+            if (std::memcmp(&a.m[4 * c + r], &b.m[4 * c + r], 4) != 0 || std::memcmp(&a.inv_m[4 * c + r], &b.inv_m[4 * c + r], 4) != 0) return false;
+          }
+        return true;
+      };
+      uint32_t k = 0;
+      while (k < class_first.size() && !same(s->objects[class_first[k]], s->objects[i])) ++k;
+      if (k == class_first.size()) class_first.push_back(i);
+      ctx->sphere_class[i] = k + 1u;
+    }
+    if (int rc = upload(ctx, ctx->scene_allocs, &d.sphere_ball, balls.data(), balls.size())) return rc;
+  }
   lap(times.copy_ms);
 
   // ---- phase 3: per mesh, the arrays of the reference layout and the layouts for the fast traversals (wide inner
@@ -1143,6 +1255,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->min_waves = (uint32_t)value;
     return PTC_OK;
   }
+  if (std::strcmp(name, "sphere_lanes") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "sphere_lanes must be 0 or 1");
+    ctx->sphere_lanes = value != 0;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "split_idle") == 0) {
     if (value < 0 || value > 64) return fail(ctx, PTC_ERR_INVALID, "split_idle must be in [0,64]");
     ctx->split_idle = (uint32_t)value;
@@ -1300,6 +1417,17 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   return PTC_OK;
 }
 
+// may the sphere run [begin, end) take the per-lane path (sphere_run_lanes)?
+static uint32_t lanes_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
+{
+  if (!ctx->sphere_lanes || end <= begin || end - begin > 8u || end > ctx->sphere_class.size()) return 0u;
+  const uint32_t k = ctx->sphere_class[begin];
+  if (k == 0u) return 0u;
+  for (uint32_t i = begin; i < end; ++i)
+    if (ctx->sphere_class[i] != k) return 0u;
+  return 1u;
+}
+
 int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
 {
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
@@ -1343,6 +1471,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       const bool by_spheres = ctx->filter_rays && l.pre_begin < l.pre_end && !sorted && ctx->trace_variant == 3;
       const bool listed = by_spheres || (bounce == 0 && k == 0 && sl.first_listed);  // (bounce 0's first launch: listed by k_raygen)
       if (l.pre_begin < l.pre_end) {
+        scene.lanes_run = lanes_run_of(ctx, l.pre_begin, l.pre_end);
         launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi,
                        by_spheres ? l.mesh : 0u, by_spheres ? l.mesh + (uint32_t)run : 0u, by_spheres ? sl.worklist : nullptr,
                        sl.tile_desc, sl.tile_stride, by_spheres ? next_epoch(sl) : 0u);
@@ -1378,6 +1507,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   if (ctx->fused_shade) {
     // one pass: trailing spheres + material + stable compaction (decoupled look-back) + final gather
     next_epoch(sl);
+    scene.lanes_run = tail ? lanes_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
     launch_shade_fused(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, out, sl.hits, ctx->pix_count,
                        ctx->staging(), bounce, last, slot_base_dev, sl.tile_desc, sl.tile_stride, sl.shade_epoch, sl.stage, ctx->band,
                        sl.counters, octs, sl.bi, bounce == 0 && sl.primary_finished ? sl.worklist : nullptr);
