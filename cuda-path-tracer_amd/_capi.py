@@ -155,6 +155,9 @@ SIGNATURES = {
     "ptc_make_object": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(ptc_sphere),
                                    C.POINTER(C.c_float), C.POINTER(ptc_object)]),
     "ptc_check_traversal_layout": (C.c_int, [C.POINTER(ptc_bvh_node), C.c_uint32, C.POINTER(C.c_uint64)]),
+    "ptc_check_beam": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.POINTER(C.c_uint64), C.c_void_p]),
+    "ptc_debug_beam_entries": (C.c_int, [_P, C.POINTER(ptc_camera), C.c_void_p, C.c_uint64]),
     "ptc_selftest_math": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }

@@ -101,6 +101,41 @@ struct DMeshView {
   uint32_t bvh_node_count;
 };
 
+// Which pixels of the frame this context renders.  Contiguous (nranks == 1): pixel = pix_begin + s.
+// Interleaved (multi-GPU, load-balanced): the frame is cut into blocks of `block_rows` rows dealt round-robin to
+// `nranks` contexts; local row lr is row ((lr / block_rows) * nranks + rank) * block_rows + lr % block_rows.
+struct DBand {
+  uint32_t pix_begin, width, rank, nranks, block_rows;
+};
+PT_HD uint32_t band_pixel(const DBand& b, uint32_t s)
+{
+  if (b.nranks <= 1u) return b.pix_begin + s;
+  const uint32_t lr = s / b.width, x = s - lr * b.width;
+  const uint32_t y = ((lr / b.block_rows) * b.nranks + b.rank) * b.block_rows + lr % b.block_rows;
+  return y * b.width + x;
+}
+PT_HD uint32_t band_local(const DBand& b, uint32_t pixel)
+{
+  if (b.nranks <= 1u) return pixel - b.pix_begin;
+  const uint32_t y = pixel / b.width, x = pixel - y * b.width;
+  const uint32_t lr = ((y / b.block_rows) / b.nranks) * b.block_rows + y % b.block_rows;
+  return lr * b.width + x;
+}
+
+// Entry points for primary rays ("beam", round 4): per distinct camera of a batch and per tile of kBeamTile x kBeamTile
+// pixels, the (at most four) deepest nodes of the launch's four-wide tree that the tile's frustum overlaps, each with its
+// box in the object's space: 2 float4 per entry {box min, reference bits} {box max, 0}, 4 entries per tile (unused:
+// an inside-out box).  A primary ray tests the four boxes of its tile like the children of one node and starts its walk
+// there instead of at the root (k_beam writes them, k_traverse4<.., kBeam> reads them).
+constexpr uint32_t kBeamTile = 8u;
+constexpr uint32_t kBeamEntries = 4u;
+struct DBeam {
+  const float4* entries;        // null: off
+  uint32_t tiles_x, tiles;      // tiles per row, tiles per camera
+  uint32_t width;               // of the frame, pixels
+  DBand band;                   // which pixel a slot of bounce 0 holds (band_pixel)
+  uint8_t beam_of[32];          // frame of the batch -> camera of the batch (frames with the same camera share one)
+};
 constexpr uint32_t kSphereTab = 8u;  // float4 per object in DScene::sphere_ball
 struct DScene {
   const DObject* objects;
@@ -130,6 +165,7 @@ struct DScene {
   // {sphere centre, .. z}, {translation, sphere radius}, {material bits, 0, 0, 0} (sphere_run_lanes).
   const float4* sphere_ball;
   uint32_t lanes_run;              // set per launch by the host: the launch's sphere run may take sphere_run_lanes
+  DBeam beam;                      // set per launch by the host (bounce 0's first traversal launch, or off)
 };
 
 // Camera constants prepared on the host once per frame (GPUCamera, camera.hpp:10-15, plus the
@@ -141,27 +177,6 @@ struct DCamera {
   float llx, lly;    // lower-left corner x, y  ( = -(vw/2), -(vh/2) )
   uint32_t width, height;
 };
-
-// Which pixels of the frame this context renders.  Contiguous (nranks == 1): pixel = pix_begin + s.
-// Interleaved (multi-GPU, load-balanced): the frame is cut into blocks of `block_rows` rows dealt round-robin to
-// `nranks` contexts; local row lr is row ((lr / block_rows) * nranks + rank) * block_rows + lr % block_rows.
-struct DBand {
-  uint32_t pix_begin, width, rank, nranks, block_rows;
-};
-PT_HD uint32_t band_pixel(const DBand& b, uint32_t s)
-{
-  if (b.nranks <= 1u) return b.pix_begin + s;
-  const uint32_t lr = s / b.width, x = s - lr * b.width;
-  const uint32_t y = ((lr / b.block_rows) * b.nranks + b.rank) * b.block_rows + lr % b.block_rows;
-  return y * b.width + x;
-}
-PT_HD uint32_t band_local(const DBand& b, uint32_t pixel)
-{
-  if (b.nranks <= 1u) return pixel - b.pix_begin;
-  const uint32_t y = pixel / b.width, x = pixel - y * b.width;
-  const uint32_t lr = ((y / b.block_rows) / b.nranks) * b.block_rows + y % b.block_rows;
-  return lr * b.width + x;
-}
 
 // Live-path state, one float4 per path and array (48 B/path):
 //   o4 = origin.xyz, bits(pixel | tmin_flag<<31)   tmin_flag: t_min is 1e-5 (after a dielectric) instead of 1e-4
@@ -289,6 +304,9 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
 void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                          DHits hits, int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                          uint32_t* slow_list, const uint32_t* order, const DBatchInfo& bi, bool listed = false);
+// the entry points of `nbeam` cameras (cams.c[cam_of[b]]) for the mesh object obj_index, into `out` (DBeam::entries)
+void launch_beam(hipStream_t s, const DScene& scene, uint32_t obj_index, const DCameras& cams, const uint8_t* cam_of, uint32_t nbeam,
+                 uint32_t tiles_x, uint32_t tiles_y, uint32_t node_count4, float4* out);
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                      uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi, bool listed = false);

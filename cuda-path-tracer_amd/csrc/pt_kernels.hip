@@ -20,6 +20,7 @@
 
 #include "pt_device.hpp"
 #include "pt_rng.hpp"
+#include "pt_beam_rules.hpp"
 
 #include <float.h>
 
@@ -1402,7 +1403,7 @@ __device__ __forceinline__ void set_aside(DeviceCounters* counters, uint32_t* sl
   __hip_atomic_store(&slow_list[at], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool kCount, bool kFirst>
+template <bool kCount, bool kFirst, bool kBeam>
 __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
                                                int bounce, int work_slot, DeviceCounters* counters, uint32_t* slow_list,
                                                const uint32_t* order, const DBatchInfo& bi, const bool listed)
@@ -1808,6 +1809,18 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
         slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
         const float4 o4 = ldnt(&paths.o4[slot]);
         const float4 d4 = ldnt(&paths.d4[slot]);
+        // entry points (DBeam): the tile's four boxes, requested together with the ray -- at bounce 0 the slot says which
+        // pixel the ray belongs to, so the address does not wait for the ray (one round trip for both; the first version
+        // took the pixel from the loaded ray and paid a second one, in front of every lane of the wavefront)
+        float4 eb[kBeam ? 8 : 1];
+        if (kBeam) {
+          const uint32_t frame = slot / bi.stride;
+          const uint32_t pixel = band_pixel(sc.beam.band, slot - frame * bi.stride);
+          const uint32_t py = pixel / sc.beam.width, px = pixel - py * sc.beam.width;
+          const float4* e = sc.beam.entries + ((size_t)sc.beam.beam_of[frame] * sc.beam.tiles + (size_t)(py / kBeamTile) * sc.beam.tiles_x + px / kBeamTile) * (2u * kBeamEntries);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) eb[k] = e[k];
+        }
         ro = xyz(o4);
         rd = xyz(d4);
         tmin = (__float_as_uint(o4.w) >> 31) ? 1e-5f : 1e-4f;
@@ -1862,6 +1875,43 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
             cur = sc.cur.bvh4_root;
             sp = sbase = 0;
             ray_boxes = 0u;
+            if (kBeam) {
+              // entry points (DBeam): the four boxes of the ray's tile, tested like the children of one node -- same
+              // conservative slab arithmetic, boxes in the object's space -- and entered nearest first.  Everything the
+              // tile's frustum cannot reach was left out by k_beam; what the walk finds is verified exactly as always.
+              float key[4];
+              uint32_t ref[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float4 lo = eb[2 * c], hi = eb[2 * c + 1];
+                const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(neg_x ? hi.x : lo.x, inv.x, oin.x), __builtin_fmaf(neg_y ? hi.y : lo.y, inv.y, oin.y)),
+                                             __builtin_fmaf(neg_z ? hi.z : lo.z, inv.z, oin.z)), 0.0f);
+                const float tf = fminf(fminf(fminf(__builtin_fmaf(neg_x ? lo.x : hi.x, inv.x, oif.x), __builtin_fmaf(neg_y ? lo.y : hi.y, inv.y, oif.y)),
+                                             __builtin_fmaf(neg_z ? lo.z : hi.z, inv.z, oif.z)), limit);
+                key[c] = tn <= tf ? tn : __builtin_inff();
+                ref[c] = __float_as_uint(lo.w);
+                if (kCount && key[c] < __builtin_inff()) { ++tally.boxes; ++ray_boxes; }
+              }
+              auto cx = [&](int a, int b) {
+                const bool sw = key[b] < key[a];
+                const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];
+                const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];
+                key[a] = ka;
+                key[b] = kb;
+                ref[a] = ra;
+                ref[b] = rb;
+              };
+              cx(0, 1);
+              cx(2, 3);
+              cx(0, 2);
+              cx(1, 3);
+              cx(1, 2);
+              if (key[3] < __builtin_inff()) push(ref[3]);
+              if (key[2] < __builtin_inff()) push(ref[2]);
+              if (key[1] < __builtin_inff()) push(ref[1]);
+              cur = ref[0];
+              go = key[0] < __builtin_inff();  // (no entry hit: the ray passes this object)
+            }
           }
         }
         if (go) active = true;
@@ -1987,12 +2037,58 @@ __device__ __forceinline__ void redo_slow_rays(const DScene& sc, uint32_t obj_in
   if (flags) atomicOr(&counters->flags, flags);
 }
 
-template <bool kCount, bool kFirst>
+// Entry points for primary rays (DBeam), one thread per tile and camera.  The tile's frustum: four planes through the
+// camera, each spanned by two neighbouring corner rays of the tile's pixel rectangle (generate_ray at the rectangle's
+// corners, a twentieth of a pixel outside: the jitter keeps a ray of pixel x inside [x, x + 1]); everything in the space
+// of the launch's object (the walk's space).  A box is out when its corner farthest along a plane's normal is still
+// outside that plane by more than the margin; the pyramid is the forward one only, so what lies behind the camera is out
+// -- the reference's line-without-range box test would pass such boxes, but no triangle in them can be hit at t >= t_min.
+// Frontier: the root; as long as there is room for them, the largest inner entry is replaced by those of its (quantised)
+// children the frustum reaches.  Quantised boxes contain the exact ones and are handed on a millionth larger: the rays
+// test them with the walk's own tolerant slabs, and the winner is verified exactly (finalize) as for any other walk.
+__global__ __launch_bounds__(64) void k_beam(DScene sc, uint32_t obj_index, DCameras cams, DBeam geo, uint32_t nbeam, uint32_t node_count4, float4* out)
+{
+  const uint32_t id = blockIdx.x * 64u + threadIdx.x;
+  if (id >= nbeam * geo.tiles) return;
+  const uint32_t beam = id / geo.tiles, tile = id - beam * geo.tiles;
+  const uint32_t ty = tile / geo.tiles_x, tx = tile - ty * geo.tiles_x;
+  const DCamera& cam = cams.c[geo.beam_of[beam]];  // (here: the camera OF the beam, filled in by launch_beam)
+  const DObject* obj = sc.objects + obj_index;
+  const float x0 = (float)(tx * kBeamTile) - 0.05f, x1 = (float)((tx + 1u) * kBeamTile) + 0.05f;
+  const float y0 = (float)(ty * kBeamTile) - 0.05f, y1 = (float)((ty + 1u) * kBeamTile) + 0.05f;
+  f3 o, d00, d10, d01, d11, dc;
+  generate_ray(cam, x0, y0, o, d00);
+  generate_ray(cam, x1, y0, o, d10);
+  generate_ray(cam, x0, y1, o, d01);
+  generate_ray(cam, x1, y1, o, d11);
+  generate_ray(cam, 0.5f * (x0 + x1), 0.5f * (y0 + y1), o, dc);
+  const beam_rules::Frustum fr = beam_rules::make_frustum(xform_point(obj->inv_m, o), xform_vector(obj->inv_m, d00), xform_vector(obj->inv_m, d10),
+                                                          xform_vector(obj->inv_m, d01), xform_vector(obj->inv_m, d11), xform_vector(obj->inv_m, dc));
+  f3 lo4[4], hi4[4];
+  uint32_t ref4[4];
+  int n = 0;
+  if (sc.cur.bvh_node_count != 0u)
+    n = beam_rules::tile_entries(reinterpret_cast<const uint32_t*>(sc.cur.bvh4q), node_count4, sc.cur.bvh4_root, ld3(sc.cur.root_min), ld3(sc.cur.root_max), fr,
+                                 lo4, hi4, ref4);
+  float4* e = out + (size_t)id * (2u * kBeamEntries);
+#pragma unroll
+  for (int k = 0; k < (int)kBeamEntries; ++k) {
+    if (k < n) {
+      e[2 * k] = make_float4(lo4[k].x, lo4[k].y, lo4[k].z, __uint_as_float(ref4[k]));
+      e[2 * k + 1] = make_float4(hi4[k].x, hi4[k].y, hi4[k].z, 0.0f);
+    } else {  // nothing: a box no ray is inside of
+      e[2 * k] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __uint_as_float(kNoChild));
+      e[2 * k + 1] = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.0f);
+    }
+  }
+}
+
+template <bool kCount, bool kFirst, bool kBeam = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES)))
 void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bounce, int work_slot,
                  DeviceCounters* counters, uint32_t* slow_list, const uint32_t* order, DBatchInfo bi, int listed)
 {
-  traverse4_walk<kCount, kFirst>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed != 0);
+  traverse4_walk<kCount, kFirst, kBeam>(sc, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed != 0);
   // Epilogue: every wavefront signs off; the last one redoes the rays that were set aside.  The list entries were
   // written with agent-scope atomic stores; waiting for this wavefront's own stores before the sign-off and reading
   // the list with agent-scope loads orders them without a full L2 write-back per wavefront.
@@ -3088,11 +3184,26 @@ void launch_traverse_run(hipStream_t s, const DScene& scene, uint32_t obj_begin,
     else hipLaunchKernelGGL((k_traverse4m<false, false>), grid, block, 0, s, scene, obj_begin, obj_end, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
   }
 }
+void launch_beam(hipStream_t s, const DScene& scene, uint32_t obj_index, const DCameras& cams, const uint8_t* cam_of, uint32_t nbeam,
+                 uint32_t tiles_x, uint32_t tiles_y, uint32_t node_count4, float4* out)
+{
+  DBeam geo{};
+  geo.tiles_x = tiles_x;
+  geo.tiles = tiles_x * tiles_y;
+  for (uint32_t b = 0; b < nbeam && b < 32u; ++b) geo.beam_of[b] = cam_of[b];
+  const uint32_t threads = nbeam * geo.tiles;
+  hipLaunchKernelGGL(k_beam, dim3((threads + 63u) / 64u), dim3(64), 0, s, scene, obj_index, cams, geo, nbeam, node_count4, out);
+}
 void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, bool first, DPaths paths, DHits hits,
                      int bounce, int work_slot, DeviceCounters* counters, bool count_tests, uint32_t waves,
                      uint32_t* slow_list, const uint32_t* order, int variant, const DBatchInfo& bi, bool listed)
 {
   const dim3 grid(waves), block(kWave);
+  if (scene.beam.entries && first) {  // bounce 0's first launch: primary rays start at their tile's entry points
+    if (count_tests) hipLaunchKernelGGL((k_traverse4<true, true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
+    else hipLaunchKernelGGL((k_traverse4<false, true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
+    return;
+  }
   if (count_tests) {
     if (first) hipLaunchKernelGGL((k_traverse4<true, true>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
     else hipLaunchKernelGGL((k_traverse4<true, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);

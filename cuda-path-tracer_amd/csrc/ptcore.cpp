@@ -26,6 +26,7 @@
 
 #include "pt_device.hpp"
 #include "pt_host.hpp"
+#include "pt_beam_rules.hpp"
 
 using namespace pt;
 
@@ -63,6 +64,7 @@ struct ptc_ctx {
   ptc_upload_times upload_times{};
   std::vector<DMeshView> mesh_views;   // host copy of DScene::mesh_views: a traversal launch gets its object's mesh as DScene::cur
   std::vector<uint32_t> object_mesh;
+  std::vector<uint32_t> mesh_nodes4;   // four-wide nodes of every mesh (k_beam's range check)
 
   // frame
   uint32_t width = 0, height = 0;
@@ -82,6 +84,8 @@ struct ptc_ctx {
     unsigned long long* tile_desc = nullptr;  // k_shade_fused: look-back descriptors, tile_stride per frame of the batch
     uint32_t tile_stride = 0;
     uint32_t shade_epoch = 0;           // look-back launches on these descriptors so far (1 .. 2^30 - 1, then round again)
+    float4* beam_entries = nullptr; // "beam": entry points of the batch's cameras (DBeam), capacity x tiles x 8 float4
+    DBeam beam{};                   // ... as bounce 0's first traversal launch gets them (entries null: off for this batch)
     uint32_t* slow_list = nullptr;  // slots of rays set aside for the exact redo at the end of a traversal launch
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
@@ -173,6 +177,8 @@ struct ptc_ctx {
   // matrix entries outside the translation columns; a run of one class (at most eight objects) takes sphere_run_lanes
   std::vector<uint32_t> sphere_class;
   bool sphere_lanes = true;   // "sphere_lanes"
+  bool beam = true;           // "beam": primary rays start at their tile's entry points (k_beam)
+  uint32_t beam_tiles_x = 0, beam_tiles_y = 0;
   uint32_t traverse_waves = 5120;
   uint32_t refill_lanes = 20;
   uint32_t static_eighths = 3;
@@ -878,7 +884,11 @@ int ptc_upload_scene(ptc_ctx* ctx, const ptc_scene_desc* s)
     lap(times.triangles_ms);
   }
   ctx->mesh_views.clear();
-  for (const MeshWork& w : meshes) ctx->mesh_views.push_back(w.view);
+  ctx->mesh_nodes4.clear();
+  for (const MeshWork& w : meshes) {
+    ctx->mesh_views.push_back(w.view);
+    ctx->mesh_nodes4.push_back(w.w4_nodes);
+  }
   ctx->object_mesh = object_mesh;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.mesh_views, ctx->mesh_views.data(), ctx->mesh_views.size())) return rc;
   if (int rc = upload(ctx, ctx->scene_allocs, &d.object_mesh, object_mesh.data(), object_mesh.size())) return rc;
@@ -1057,6 +1067,11 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     sl.shade_epoch = 0;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_stack, (size_t)kStackDepth * kWave)) return rc;
+    if (ctx->beam) {
+      ctx->beam_tiles_x = (width + kBeamTile - 1u) / kBeamTile;    // (ctx->width is set when everything has been allocated)
+      ctx->beam_tiles_y = (height + kBeamTile - 1u) / kBeamTile;
+      if (int rc = dev_alloc(ctx, pool, &sl.beam_entries, (size_t)B * ctx->beam_tiles_x * ctx->beam_tiles_y * 2u * kBeamEntries)) return rc;
+    }
     if (int rc = dev_alloc(ctx, pool, &sl.worklist, BP)) return rc;
     if (ctx->ray_sort) {
       if (int rc = dev_alloc(ctx, pool, &sl.octs, BP)) return rc;
@@ -1255,6 +1270,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->min_waves = (uint32_t)value;
     return PTC_OK;
   }
+  if (std::strcmp(name, "beam") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "beam must be 0 or 1");
+    if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set beam before ptc_resize");
+    ctx->beam = value != 0;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "sphere_lanes") == 0) {
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "sphere_lanes must be 0 or 1");
     ctx->sphere_lanes = value != 0;
@@ -1413,6 +1434,31 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
                 sl.first_listed ? sl.worklist : nullptr, sl.hits, sl.tile_desc, sl.tile_stride, next_epoch(sl), sl.primary_finished,
                 sl.stage, ctx->staging());
   if (int rc = check_last(ctx, "raygen")) return rc;
+  // "beam": when bounce 0 opens with a launch over ONE mesh object (k_traverse4), its primary rays start at entry points
+  // computed per tile and distinct camera of the batch
+  sl.beam = DBeam{};
+  if (ctx->beam && sl.beam_entries && ctx->trace_variant == 3 && !ctx->launches.empty() && ctx->launches[0].pre_begin == ctx->launches[0].pre_end &&
+      launch_run(ctx, 0) == 1 && ctx->width >= 2u && ctx->height >= 2u) {
+    uint8_t cam_of_beam[kMaxBatch];
+    uint32_t nbeam = 0;
+    for (int k = 0; k < count; ++k) {
+      uint32_t b = 0;
+      while (b < nbeam && std::memcmp(&cams.c[cam_of_beam[b]], &cams.c[k], sizeof(DCamera)) != 0) ++b;
+      if (b == nbeam) cam_of_beam[nbeam++] = (uint8_t)k;
+      sl.beam.beam_of[k] = (uint8_t)b;
+    }
+    DScene scene = ctx->scene;
+    const uint32_t mesh_obj = ctx->launches[0].mesh;
+    scene.cur = ctx->mesh_views[ctx->object_mesh[mesh_obj]];
+    launch_beam(sl.stream, scene, mesh_obj, cams, cam_of_beam, nbeam, ctx->beam_tiles_x, ctx->beam_tiles_y, ctx->mesh_nodes4[ctx->object_mesh[mesh_obj]],
+                sl.beam_entries);
+    if (int rc = check_last(ctx, "beam")) return rc;
+    sl.beam.entries = sl.beam_entries;
+    sl.beam.tiles_x = ctx->beam_tiles_x;
+    sl.beam.tiles = ctx->beam_tiles_x * ctx->beam_tiles_y;
+    sl.beam.width = ctx->width;
+    sl.beam.band = ctx->band;
+  }
   ctx->active_slot = f;
   return PTC_OK;
 }
@@ -1488,6 +1534,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
         k += run - 1;
       } else {
         const int kernel = ctx->trace_variant;
+        scene.beam = (bounce == 0 && k == 0) ? sl.beam : DBeam{};
         launch_traverse(sl.stream, scene, l.mesh, !wrote, in, sl.hits, bounce, sl.work_slot++ % kWorkSlots, sl.counters, ctx->count_tests, waves,
                         sl.slow_list, pick, kernel, sl.bi, listed);
       }
@@ -2209,6 +2256,182 @@ int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_s
                     ptc_object* out)
 {
   return make_object(type, index, m16, sphere, mesh_aabb6, out);
+}
+
+// Entry points for primary rays (pt_beam_rules.hpp) checked on the host: for a mesh, an object matrix, a camera and a
+// resolution, every tile's entries as k_beam computes them (same functions), then for sample rays of the tile -- the
+// corners and the centre of the jitter range of every `stride`-th pixel -- the closest hit of a plain walk over the
+// four-wide quantised tree started at the ROOT against the same walk started at the tile's ENTRIES: triangle and t must
+// agree.  Returns the number of rays that disagree (0 = sound), or a negative status; stats (may be NULL): tiles, tiles
+// without entries, entries in total, rays checked, rays that hit.
+int ptc_check_beam(const float* positions, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count, const float* object_m16,
+                   const ptc_camera* camera, uint32_t width, uint32_t height, uint32_t stride, uint64_t* stats5, float* entries_out)
+{
+  if (!positions || !indices || !camera || index_count == 0u || index_count % 3u || width < 2u || height < 2u || stride == 0u) return PTC_ERR_INVALID;
+  std::vector<ptc_bvh_node> nodes((size_t)index_count / 3u * 2u);
+  uint32_t depth = 0;
+  const int rc = build_bvh(positions, vertex_count, indices, index_count, nodes.data(), &depth);
+  if (rc < 0) return rc;
+  WideAccel wide;
+  if (int r = build_wide(nodes.data(), (uint32_t)rc, wide)) return r;
+  Wide4Accel w4;
+  if (int r = build_wide4(nodes.data(), (uint32_t)rc, w4)) return r;
+  m4 m{};
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) m.c[c][r] = object_m16 ? object_m16[4 * c + r] : (c == r ? 1.0f : 0.0f);
+  const m4 inv_m = inverse(m);
+  const DCamera cam = make_camera(*camera, width, height);
+  auto gen = [&](float fx, float fy, f3& o, f3& d) {  // generate_ray (pt_kernels.hip), the same operations
+    const float u = fx / (float)(cam.width - 1u);
+    const float v = ((float)cam.height - fy) / (float)(cam.height - 1u);
+    const float dx = cam.llx + cam.vw * u;
+    const float dy = cam.lly + cam.vh * v;
+    o = cam.origin;
+    d = normalize(xform_vector(cam.cam, mk3(dx, dy, -1.0f)));
+  };
+  const uint32_t* nq = w4.nodes_q.data();
+  const uint32_t n4 = (uint32_t)(w4.nodes_q.size() / 16u);
+  const f3 root_lo = mk3(wide.root_min[0], wide.root_min[1], wide.root_min[2]), root_hi = mk3(wide.root_max[0], wide.root_max[1], wide.root_max[2]);
+  // closest hit of the plain walk from a set of start references (boxes tested first)
+  struct HitRec { bool hit; uint32_t rank; float t; };
+  auto slab = [](const f3 lo, const f3 hi, const f3 o, const f3 inv, float tmax) {
+    float tn = 0.0f, tf = tmax;
+    const float lo_[3] = {lo.x, lo.y, lo.z}, hi_[3] = {hi.x, hi.y, hi.z}, o_[3] = {o.x, o.y, o.z}, i_[3] = {inv.x, inv.y, inv.z};
+    for (int a = 0; a < 3; ++a) {
+      const float t0 = (lo_[a] - o_[a]) * i_[a], t1 = (hi_[a] - o_[a]) * i_[a];
+      tn = std::max(tn, std::min(t0, t1));
+      tf = std::min(tf, std::max(t0, t1));
+    }
+    return tn <= tf * 1.000001f + 1e-6f;
+  };
+  auto walk = [&](const f3 o, const f3 d, const f3* lo4, const f3* hi4, const uint32_t* ref4, int n) {
+    HitRec best{false, 0u, 3.0e38f};
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    std::vector<uint32_t> stack;
+    for (int k = 0; k < n; ++k)
+      if (slab(lo4[k], hi4[k], o, inv, best.t)) stack.push_back(ref4[k]);
+    while (!stack.empty()) {
+      const uint32_t ref = stack.back();
+      stack.pop_back();
+      if (ref & kLeafBit) {
+        const uint32_t rank = ref & ~kLeafBit;
+        if (rank >= wide.tri_order.size()) continue;  // the dummy
+        const uint32_t tri = wide.tri_order[rank];
+        const f3 p0 = mk3(positions[3 * indices[3 * tri]], positions[3 * indices[3 * tri] + 1], positions[3 * indices[3 * tri] + 2]);
+        const f3 p1 = mk3(positions[3 * indices[3 * tri + 1]], positions[3 * indices[3 * tri + 1] + 1], positions[3 * indices[3 * tri + 1] + 2]);
+        const f3 p2 = mk3(positions[3 * indices[3 * tri + 2]], positions[3 * indices[3 * tri + 2] + 1], positions[3 * indices[3 * tri + 2] + 2]);
+        const f3 e1 = p1 - p0, e2 = p2 - p0, h = cross(d, e2);
+        const float a = dot(e1, h);
+        if (a > -1e-12f && a < 1e-12f) continue;
+        const float f = 1.0f / a;
+        const f3 sv = o - p0;
+        const float u = f * dot(sv, h);
+        if (u < 0.0f || u > 1.0f) continue;
+        const f3 q = cross(sv, e1);
+        const float v = f * dot(d, q);
+        if (v < 0.0f || u + v > 1.0f) continue;
+        const float t = f * dot(e2, q);
+        if (t < 1e-4f) continue;
+        if (t < best.t || (t == best.t && rank > best.rank)) best = HitRec{true, rank, t};
+        continue;
+      }
+      if (ref >= n4) return HitRec{true, 0xffffffffu, -1.0f};  // a reference out of range: reported as a disagreement
+      const uint32_t* q = nq + 16u * (size_t)ref;
+      for (int c = 0; c < 4; ++c) {
+        f3 lo, hi;
+        if (!beam_rules::child_box(q, c, lo, hi)) continue;
+        if (slab(lo, hi, o, inv, best.t)) stack.push_back(q[12 + c]);
+      }
+    }
+    return best;
+  };
+  uint64_t tiles = 0, empty = 0, entries = 0, rays = 0, hits = 0;
+  int bad = 0;
+  const uint32_t tiles_x = (width + kBeamTile - 1u) / kBeamTile, tiles_y = (height + kBeamTile - 1u) / kBeamTile;
+  const uint32_t root_ref4[1] = {w4.root_ref};
+  for (uint32_t ty = 0; ty < tiles_y; ++ty)
+    for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+      const float x0 = (float)(tx * kBeamTile) - 0.05f, x1 = (float)((tx + 1u) * kBeamTile) + 0.05f;
+      const float y0 = (float)(ty * kBeamTile) - 0.05f, y1 = (float)((ty + 1u) * kBeamTile) + 0.05f;
+      f3 o, d00, d10, d01, d11, dc;
+      gen(x0, y0, o, d00);
+      gen(x1, y0, o, d10);
+      gen(x0, y1, o, d01);
+      gen(x1, y1, o, d11);
+      gen(0.5f * (x0 + x1), 0.5f * (y0 + y1), o, dc);
+      const beam_rules::Frustum fr = beam_rules::make_frustum(xform_point(inv_m, o), xform_vector(inv_m, d00), xform_vector(inv_m, d10),
+                                                              xform_vector(inv_m, d01), xform_vector(inv_m, d11), xform_vector(inv_m, dc));
+      f3 lo4[4], hi4[4];
+      uint32_t ref4[4];
+      const int n = beam_rules::tile_entries(nq, n4, w4.root_ref, root_lo, root_hi, fr, lo4, hi4, ref4);
+      if (entries_out) {  // as k_beam stores them: {box min, reference bits} {box max, 0}; unused: an inside-out box
+        float* e = entries_out + ((size_t)ty * tiles_x + tx) * 32u;
+        for (int k = 0; k < 4; ++k) {
+          const float inf = __builtin_inff();
+          uint32_t ref = k < n ? ref4[k] : kNoChild;
+          float refbits;
+          std::memcpy(&refbits, &ref, 4);
+          const float rec[8] = {k < n ? lo4[k].x : inf, k < n ? lo4[k].y : inf, k < n ? lo4[k].z : inf, refbits,
+                                k < n ? hi4[k].x : -inf, k < n ? hi4[k].y : -inf, k < n ? hi4[k].z : -inf, 0.0f};
+          std::memcpy(e + 8 * k, rec, sizeof rec);
+        }
+      }
+      ++tiles;
+      empty += n == 0;
+      entries += (uint64_t)n;
+      for (int k = 0; k < n; ++k)
+        if (!(ref4[k] & kLeafBit) && ref4[k] >= n4) ++bad;
+      for (uint32_t py = ty * kBeamTile; py < std::min(height, (ty + 1u) * kBeamTile); py += stride)
+        for (uint32_t px = tx * kBeamTile; px < std::min(width, (tx + 1u) * kBeamTile); px += stride) {
+          const float jit[5][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {0.0f, 1.0f}, {1.0f, 1.0f}, {0.5f, 0.5f}};  // (uniform_real can round to 1)
+          for (const auto& j : jit) {
+            f3 ro, rd;
+            gen((float)px + j[0], (float)py + j[1], ro, rd);
+            const f3 oo = xform_point(inv_m, ro), od = xform_vector(inv_m, rd);
+            const HitRec a = walk(oo, od, &root_lo, &root_hi, root_ref4, 1);
+            const HitRec b = walk(oo, od, lo4, hi4, ref4, n);
+            ++rays;
+            hits += a.hit;
+            if (a.hit != b.hit || (a.hit && (a.rank != b.rank || a.t != b.t))) ++bad;
+          }
+        }
+    }
+  if (stats5) {
+    stats5[0] = tiles;
+    stats5[1] = empty;
+    stats5[2] = entries;
+    stats5[3] = rays;
+    stats5[4] = hits;
+  }
+  return bad;
+}
+
+// Test hook: the entries k_beam computes on the GPU for the uploaded scene's first traversal launch (its mesh object) and
+// `camera` at the context's resolution, [tiles][4][8 floats] as ptc_check_beam lays them out.
+int ptc_debug_beam_entries(ptc_ctx* ctx, const ptc_camera* camera, float* entries_out, uint64_t capacity_floats)
+{
+  if (!ctx || !camera || !entries_out) return PTC_ERR_INVALID;
+  if (!ctx->has_scene || !ctx->pix_capacity || ctx->launches.empty()) return fail(ctx, PTC_ERR_INVALID, "no scene / frame / mesh launch");
+  if (int rc = bind_device(ctx)) return rc;
+  if (int rc = sync_frames(ctx)) return rc;
+  const uint32_t tx = (ctx->width + kBeamTile - 1u) / kBeamTile, ty = (ctx->height + kBeamTile - 1u) / kBeamTile;
+  const size_t floats = (size_t)tx * ty * 32u;
+  if (capacity_floats < floats) return fail(ctx, PTC_ERR_INVALID, "entries_out too small");
+  float4* dev = nullptr;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dev), floats * sizeof(float)));
+  DCameras cams{};
+  cams.c[0] = make_camera(*camera, ctx->width, ctx->height);
+  const uint8_t cam_of[1] = {0};
+  DScene scene = ctx->scene;
+  const uint32_t mesh_obj = ctx->launches[0].mesh;
+  scene.cur = ctx->mesh_views[ctx->object_mesh[mesh_obj]];
+  launch_beam(ctx->stream, scene, mesh_obj, cams, cam_of, 1u, tx, ty, ctx->mesh_nodes4[ctx->object_mesh[mesh_obj]], dev);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(entries_out, dev, floats * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(ctx, PTC_ERR_HIP, std::string("beam entries: ") + hipGetErrorString(e));
+  return PTC_OK;
 }
 
 int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, uint64_t* checked_boxes)

@@ -215,7 +215,16 @@ int ptc_set_denoiser_params(ptc_ctx* ctx, const ptc_denoiser_params* p); /* Path
  *   0           = traversal in the reference's own order (path_tracer.cu:36-76: depth-first, left first, no
  *                 t culling) */
 int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
-/* Tuning knobs (speed only, never results).  Known names:
+/* Knobs by name.  Three kinds (round-3 review: "they are ABI now -- mark which are stable"):
+ *   STABLE   part of the interface: meaning and default are kept, an application may rely on them
+ *              frames_in_flight, batch_frames, slot_offset, traverse_waves
+ *   SCHEDULE choose between implementations that return the SAME bits; kept for A/B measurements and as cross-checks of
+ *            each other, defaults may move with the hardware, a name may go when its alternative goes
+ *              fused_shade, filter_rays, merge_instances, sphere_lanes, beam, ray_sort, denoise_variant, bvh_build_on_device,
+ *              layout_on_device, split_idle, refill_lanes, static_eighths, small_waves, small_rays_per_lane, min_waves
+ *   TEST     hooks for the parity tests only: debug_lds_entries, debug_force_slow
+ * None of them changes a result, with one exception that is the point of it: slot_offset keys the material RNG
+ * (multi-GPU).  Unknown names return PTC_ERR_INVALID.  Known names:
  *   "frames_in_flight" consecutive iterations in flight at once, folded into the framebuffer in iteration order
  *                      (default: 64, fewer when their path state would exceed 24 GiB; 1 = strictly serial on
  *                      the context's stream; 1..256; set before ptc_resize)
@@ -258,6 +267,16 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "slot_offset"      added to every compacted slot index before the material RNG is seeded (path_tracer.cu:300).  A
  *                      rank of a multi-GPU run that numbers its paths locally (ptc_set_interleave) sets rank * (pixels of
  *                      the largest share) so that no two ranks draw the same random streams; 0 (default) = the reference
+ *   "beam"             1 (default): when a bounce-0 traversal launch walks one mesh object, a small kernel first computes, per
+ *                      8 x 8-pixel tile and distinct camera of the batch, the deepest nodes of that object's tree the tile's
+ *                      frustum overlaps (at most four, with their boxes), and the primary rays start there instead of at the
+ *                      root; 0: at the root.  Before ptc_resize
+ *   "sphere_lanes"     1 (default): in the kernel that ends a bounce, a sphere run that ends the object list and consists of
+ *                      at most eight spheres whose matrices are pure translations is tested candidate by candidate, every
+ *                      lane with the spheres IT cannot rule out ("select approximately, verify exactly": approximate bounds
+ *                      on the root the reference would accept, then the reference's own sequence for each candidate);
+ *                      0: object by object for the whole wavefront.  Any time
+ *   "min_waves"        fewest persistent wavefronts of a traversal launch (default 1024)
  *   "split_idle"       once a traversal launch has handed out its last ray: idle lanes of a persistent wavefront that
  *                      trigger work splitting (an idle lane takes over the bottom of a busy lane's traversal stack
  *                      with a copy of its ray; default 8, 0 = never).  Cuts the latency tail of every launch
@@ -400,6 +419,16 @@ int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_s
  * violations (0 = sound), or a negative ptc_status; *checked_boxes (may be NULL) gets the number of child boxes
  * looked at. */
 int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, uint64_t* checked_boxes);
+/* Entry points for primary rays ("beam"), checked on the host (no GPU): for every 8 x 8-pixel tile of a width x height
+ * frame of `camera`, the entries k_beam computes for the mesh under the object matrix object_m16 (NULL: identity;
+ * column-major), and for sample rays of the tile (corners and centre of the jitter range of every stride-th pixel) the
+ * closest hit of a walk from the tree's root against the same walk from the tile's entries.  Returns the number of rays
+ * that disagree (0 = sound) or a negative status; stats5 (may be NULL): tiles, tiles without entries, entries, rays, hits;
+ * entries_out (may be NULL): the entries themselves, [tiles][4][8 floats] = {box min, reference bits} {box max, 0}. */
+int ptc_check_beam(const float* positions, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count, const float* object_m16,
+                   const ptc_camera* camera, uint32_t width, uint32_t height, uint32_t stride, uint64_t* stats5, float* entries_out);
+/* Test hook: the same entries as k_beam computes them on the GPU for the uploaded scene's first traversal launch. */
+int ptc_debug_beam_entries(ptc_ctx* ctx, const ptc_camera* camera, float* entries_out, uint64_t capacity_floats);
 
 /* Device self-test of the arithmetic contract the parity tests rely on: evaluates IEEE divide,
  * sqrt and the deterministic sin/cos on the GPU for n inputs (host arrays in, host arrays out). */

@@ -167,3 +167,54 @@ def test_invalid_arguments_return_error_codes(pkg):
     assert lib.ptc_iteration(None) == pkg._capi.PTC_ERR_INVALID
     assert lib.ptc_make_object(2, 0, None, None, None, None) == pkg._capi.PTC_ERR_INVALID
     lib.ptc_destroy(None)  # no-op
+
+
+def _beam_check(pkg, mesh, camera, w, h, m=None, stride=3):
+    import ctypes as C
+    capi, lib = pkg._capi, pkg.lib()
+    pos = np.ascontiguousarray(mesh.positions, dtype=np.float32)
+    idx = np.ascontiguousarray(mesh.indices, dtype=np.uint32)
+    cam = capi.ptc_camera()
+    cam.position[:] = [float(x) for x in camera.position]
+    cam.rotation_wxyz[:] = [float(x) for x in camera.rotation]
+    cam.vfov = float(camera.vfov)
+    stats = (C.c_uint64 * 5)()
+    mm = None if m is None else np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(16))
+    bad = lib.ptc_check_beam(pos.ctypes.data, len(pos), idx.ctypes.data, len(idx), None if mm is None else mm.ctypes.data, C.byref(cam), w, h,
+                             stride, stats, None)
+    return bad, [int(x) for x in stats]
+
+
+def test_entry_points_of_primary_rays_are_sound(pkg):
+    """"beam" (pt_beam_rules.hpp, the functions k_beam runs on the GPU), on the host: for every 8 x 8-pixel tile the
+    entries its frustum keeps, and for the corners and the centre of the jitter range of sample pixels the closest hit of
+    a walk from those entries against the walk from the root -- cameras outside, above, inside the mesh's box, looking
+    away from it, a rotated and scaled object, frames that are no multiple of the tile, a single triangle."""
+    glm = pkg.glmlite
+    hf = pkg.scenes.heightfield_mesh(65, 33, 8.0, 4.0, seed=7)
+    ball = pkg.scenes.displaced_sphere_mesh(16, 32)
+    scene = pkg.scenes.heightfield_scene((96, 64), nx=65, nz=33)
+    cam0 = scene.camera
+    look = pkg.scenes._camera_from_look_at
+    cases = [
+        (hf, cam0, 96, 64, None),
+        (hf, cam0, 101, 67, None),                                              # ragged last tiles
+        (hf, look((0.0, 0.05, 0.0), (1.0, 0.0, 0.3), vfov_deg=70.0), 80, 48, None),     # inside the box, skimming the terrain
+        (hf, look((0.0, 3.0, 0.0), (0.0, 0.0, 0.01), vfov_deg=40.0), 64, 64, None),     # straight down
+        (hf, look((0.0, 2.0, 6.0), (0.0, 3.0, 12.0), vfov_deg=50.0), 64, 40, None),     # looking away: nothing in reach
+        (ball, look((0.0, 0.0, 0.0), (0.3, 0.2, -1.0), vfov_deg=90.0), 72, 56, None),   # from inside a closed mesh
+        (ball, look((0.5, 0.4, 2.5), (0.0, 0.0, 0.0), vfov_deg=35.0), 64, 64,
+         glm.compose([glm.rotate(np.float32(0.7), (0.3, 1.0, 0.2)), glm.scale((0.8, 0.5, 1.2)), glm.translate((0.1, -0.2, 0.3))])),
+        (pkg.scenes.heightfield_mesh(2, 2, 1.0, 1.0, seed=1), look((0.2, 1.0, 0.9), (0.0, 0.0, 0.0)), 32, 24, None),   # two triangles
+    ]
+    reached = 0
+    for mesh, cam, w, h, m in cases:
+        bad, st = _beam_check(pkg, mesh, cam, w, h, m)
+        assert bad == 0, (w, h, st)
+        tiles, empty, entries, rays, hits = st
+        assert tiles == ((w + 7) // 8) * ((h + 7) // 8) and entries <= 4 * (tiles - empty) and rays > 0
+        reached += hits
+    assert reached > 10000
+    # the case that looks away keeps nothing at all
+    _, st = _beam_check(pkg, hf, look((0.0, 2.0, 6.0), (0.0, 3.0, 12.0), vfov_deg=50.0), 64, 40)
+    assert st[1] == st[0] and st[4] == 0
