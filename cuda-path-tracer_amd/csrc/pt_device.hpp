@@ -165,6 +165,7 @@ struct DScene {
   // {sphere centre, .. z}, {translation, sphere radius}, {material bits, 0, 0, 0} (sphere_run_lanes).
   const float4* sphere_ball;
   uint32_t lanes_run;              // set per launch by the host: the launch's sphere run may take sphere_run_lanes
+  uint32_t fold_run;               // ... every object of the launch's sphere run is a "simple" sphere: k_spheres may take sphere_fold
   DBeam beam;                      // set per launch by the host (bounce 0's first traversal launch, or off)
 };
 

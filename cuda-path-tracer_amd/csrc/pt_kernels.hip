@@ -889,6 +889,9 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 #ifndef PT_SPHERE_LANES
 #define PT_SPHERE_LANES 1
 #endif
+#ifndef PT_FOLD_TAIL
+#define PT_FOLD_TAIL 0
+#endif
 #ifndef PT_SPHERE_LANES_LEADING
 #define PT_SPHERE_LANES_LEADING 0
 #endif
@@ -1021,6 +1024,125 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
   }
 }
 // ---- a run of SIMPLE sphere objects, candidates per lane (round 4) -------------------------------------------------
+// ---- a run of translated spheres as a fold with the hit record's normal deferred (round 4; k_spheres) ----
+// In front of a mesh the spheres are typically a room's walls: every ray is inside every one of them, every wall is hit,
+// and which one wins is decided only by distance -- there is nothing to rule out, so sphere_segment pays the whole
+// sequence of path_tracer.cu:84-96 + intersections.cuh:7-41 for every object (226 VALU instructions per ray and sphere
+// on the Cornell box, five walls: the launch ran at 79 % VALU issue, profiles/r04_config2_counters.txt).  When every
+// object of the run is "simple" (DScene::fold_run: both matrices pure translations, 3 x 3 part 1.0f / +-0.0f) the same
+// operations on the same operands come much cheaper:
+//   * transform_point's row (1 x + e y) + (e' z + t 1), e, e' zeros of either sign, IS x + t: the products with the
+//     zeros are zeros, they vanish in the sums, one rounding remains -- unless x is -0.0f (with t a zero the zeros'
+//     signs then decide the sign of the result; the fold does not look at t), or a coordinate is not finite (0 * inf).
+//     w is (0 x + 0 y) + (0 z + 1) = 1 and nothing is divided.  3 instructions instead of 28, for the ray's origin, and
+//     again for the hit point.
+//   * transform_normal's row (1 nx + e ny) + (e' nz + e'' 0) IS nx, unless nx is -0.0f.
+//   * what the NEXT object needs of an accepted hit is its distance (t_max: length(p_world - o)) -- the normal
+//     ((p - centre) / radius: three divisions; the side; the transform) is needed of the LAST accepted hit only: the fold
+//     keeps p - centre, the radius and the material of the hit it holds, and finishes the record once, behind the loop.
+// A lane that meets one of the exceptions (-0.0f where it matters, a non-finite coordinate, a direction with a zero
+// component: inverse_transform_ray's normalised direction is then not the same for every object) sends its wavefront
+// through sphere_segment with the ray as it came.  Same bits as sphere_segment in every case (tests/test_gpu_spheres.py).
+typedef __attribute__((address_space(4))) const float cfloat;
+__device__ __forceinline__ bool neg_zero(const float x) { return __float_as_uint(x) == 0x80000000u; }
+__device__ __forceinline__ void sphere_fold(const DScene& sc, const uint32_t obj_begin, const uint32_t obj_end, Ray& ray, Hit& rec, bool& changed)
+{
+  const bool plain = finite_f(ray.d.x + ray.d.y + ray.d.z) && ray.d.x != 0.0f && ray.d.y != 0.0f && ray.d.z != 0.0f &&
+                     finite_f(ray.o.x + ray.o.y + ray.o.z) && !neg_zero(ray.o.x) && !neg_zero(ray.o.y) && !neg_zero(ray.o.z);
+  if (__builtin_expect(__ballot(!plain) != 0ull, 0)) {
+    sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
+    return;
+  }
+  const float tmax_in = ray.tmax;
+  const f3 winv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+  const bool winv_ok = finite_f(winv.x + winv.y + winv.z);
+  const f3 nd = normalize(ray.d);  // inverse_transform_ray's direction, the same for every object of the run
+  const float a = dot(nd, nd);
+  bool odd = false;
+  f3 pc = mk3(0.f, 0.f, 0.f);      // of the hit the fold holds: p - centre (object space), the radius, the material
+  float held_r = 1.0f;
+  uint32_t held_mat = 0u;
+  const bool tmin_pos = ray.tmin > 0.0f;
+  for (uint32_t i = obj_begin; i < obj_end; ++i) {
+    // what differs between the objects of such a run, from the table the host packed (DScene::sphere_ball rows 2..6),
+    // through the constant address space: scalar loads (the object array itself is read with vector loads -- the
+    // compiler cannot know that the kernel's stores do not touch it)
+    const cfloat* q = (const cfloat*)reinterpret_cast<const float*>(sc.sphere_ball + (size_t)kSphereTab * i + 2u);
+    const f3 bmin = mk3(q[0], q[1], q[2]), bmax = mk3(q[4], q[5], q[6]);
+    const f3 itr = mk3(q[3], q[7], q[11]);         // the inverse matrix' translation column
+    const f3 center = mk3(q[8], q[9], q[10]);
+    const f3 ftr = mk3(q[12], q[13], q[14]);       // the matrix' translation column
+    const float radius = q[15];
+    const uint32_t material = __float_as_uint(q[16]);
+    {  // the object's world box (path_tracer.cu:84).  An origin strictly inside the box: every axis has one slab
+       // bound behind the origin and one in front of it, whatever the (non-zero) direction -- near < 0 < far, the
+       // reference passes; a room's walls are all of this kind, and a wavefront of such rays skips the slab arithmetic
+      const bool inside = ray.o.x > bmin.x && ray.o.x < bmax.x && ray.o.y > bmin.y && ray.o.y < bmax.y && ray.o.z > bmin.z && ray.o.z < bmax.z;
+      if (__ballot(!inside) != 0ull) {
+        // as in sphere_segment
+        const f3 a0 = (bmin - ray.o) * winv, a1 = (bmax - ray.o) * winv;
+        const float wn = fmaxf(fmaxf(fminf(a0.x, a1.x), fminf(a0.y, a1.y)), fminf(a0.z, a1.z));
+        const float wf = fminf(fminf(fmaxf(a0.x, a1.x), fmaxf(a0.y, a1.y)), fmaxf(a0.z, a1.z));
+        const float gap = wf - wn, margin = 2e-6f * (fabsf(wf) + fabsf(wn)) + 1e-30f;
+        const bool box_ok = !(bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z);
+        bool pass = gap > margin;
+        const bool unsure = !box_ok || !winv_ok || !(gap > margin || gap < -margin);
+        if (__builtin_expect(unsure, 0)) pass = ray_aabb(ray.o, ray.d, bmin, bmax);
+        if (!pass && !inside) continue;
+      }
+    }
+    Ray tr;
+    tr.o = ray.o + itr;
+    tr.d = nd;
+    // ray_sphere_intersection_test, intersections.cuh:7-41, up to the accepted root
+    const f3 oc = tr.o - center;
+    const float b = 2.0f * dot(tr.d, oc);
+    const float c = dot(oc, oc) - radius * radius;
+    const float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) continue;
+    const float sq = ieee_sqrt(disc);
+    // t1 = (-b - sq) / (2 a), 2 a > 0: a negative numerator gives a quotient that is negative or -0 and fails
+    // t1 >= t_min (> 0) without being divided; a wavefront of rays inside their spheres never divides for t1
+    const float n1 = -b - sq;
+    const bool t1_out = n1 < 0.0f && tmin_pos && a > 0.0f;
+    float t1 = -1.0f;
+    if (__ballot(!t1_out) != 0ull) {
+      asm volatile("" ::: "memory");  // (keeps the division inside the branch: the compiler would divide and select)
+      t1 = n1 / (2.0f * a);
+    }
+    float t;
+    if (!t1_out && t1 >= ray.tmin && t1 <= ray.tmax) {
+      t = t1;
+    } else {
+      const float t2 = (-b + sq) / (2.0f * a);
+      if (t2 >= ray.tmin && t2 <= ray.tmax) t = t2;
+      else continue;
+    }
+    const f3 p = ray_at(tr, t);
+    pc = p - center;
+    held_r = radius;
+    held_mat = material;
+    rec.p = p + ftr;
+    rec.t = length(rec.p - ray.o);
+    odd = odd || neg_zero(p.x) || neg_zero(p.y) || neg_zero(p.z) || !finite_f(rec.t);  // (a non-finite p gives a non-finite length)
+    ray.tmax = rec.t;
+    changed = true;
+  }
+  if (changed) {
+    const f3 outward = pc / held_r;
+    rec.side = dot(nd, outward) < 0.0f ? 0u : 1u;
+    const f3 n = rec.side == 0u ? outward : -outward;
+    odd = odd || !finite_f(n.x + n.y + n.z) || neg_zero(n.x) || neg_zero(n.y) || neg_zero(n.z);
+    rec.n = n;
+    rec.mat = held_mat;
+  }
+  if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
+    ray.tmax = tmax_in;
+    changed = false;
+    sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
+  }
+}
+
 // sphere_segment walks the run object by object, and the wavefront pays the reference's whole sequence for an object
 // whenever ANY lane cannot rule it out -- with 64 lanes that is almost every object: the Cornell box's five wall spheres
 // are all "hit" by every ray inside it, and k_spheres ran eight full sequences per ray (645 us a launch, config 2).
@@ -2141,6 +2263,7 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
   // room -- every ray hits every one of them, there is little to rule out, and sphere_segment shares the inverse
   // transform's normalised direction among them: measured 907 us against 1114 for the per-lane form, config 2)
   const bool lanes_run = PT_SPHERE_LANES_LEADING && sc.lanes_run != 0u;
+  const bool fold_run = sc.fold_run != 0u;
 #pragma unroll 1
   for (int j = 0; j < kListPer; ++j) {
     const uint32_t s = block_first + (uint32_t)j * 256u + threadIdx.x;
@@ -2162,7 +2285,8 @@ __global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, 
         ray.tmax = rtp[0].x;
       }
     } else {
-      sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
+      if (fold_run) sphere_fold(sc, obj_begin, obj_end, ray, rec, changed);
+      else sphere_segment<true>(sc, obj_begin, obj_end, ray, rec, changed);
       if (changed) store_hit(hits, s, rec);
     }
     if (!changed && kFirst) stnt(&hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
@@ -2506,7 +2630,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       ray.tmax = tp[j].x >= 0.0f ? tp[j].x : FLT_MAX;
       Hit rec;
       bool changed = false;
-      sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
+      if (PT_FOLD_TAIL && sc.fold_run != 0u) sphere_fold(sc, obj_begin, obj_end, ray, rec, changed);
+      else sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
       if (changed) {  // the record stays in registers: its only reader is this thread, a few lines down
         tp[j] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
         nm[j] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));

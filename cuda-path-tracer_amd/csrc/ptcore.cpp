@@ -181,6 +181,7 @@ struct ptc_ctx {
   // matrix entries outside the translation columns; a run of one class (at most eight objects) takes sphere_run_lanes
   std::vector<uint32_t> sphere_class;
   bool sphere_lanes = true;   // "sphere_lanes"
+  bool sphere_fold = true;    // "sphere_fold"
   bool beam = true;           // "beam": primary rays start at their tile's entry points (k_beam)
   uint64_t scene_serial = 0;  // counts ptc_upload_scene calls (entry points computed for another scene are stale)
   uint32_t beam_tiles_x = 0, beam_tiles_y = 0;
@@ -1282,6 +1283,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->beam = value != 0;
     return PTC_OK;
   }
+  if (std::strcmp(name, "sphere_fold") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "sphere_fold must be 0 or 1");
+    ctx->sphere_fold = value != 0;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "sphere_lanes") == 0) {
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "sphere_lanes must be 0 or 1");
     ctx->sphere_lanes = value != 0;
@@ -1488,6 +1494,15 @@ static uint32_t lanes_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
   return 1u;
 }
 
+// may k_spheres take sphere_fold for the run [begin, end)?  Every object a "simple" sphere (sphere_ball_of)
+static uint32_t fold_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
+{
+  if (!ctx->sphere_fold || end <= begin || end > ctx->sphere_class.size()) return 0u;
+  for (uint32_t i = begin; i < end; ++i)
+    if (ctx->sphere_class[i] == 0u) return 0u;
+  return 1u;
+}
+
 int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
 {
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
@@ -1532,6 +1547,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       const bool listed = by_spheres || (bounce == 0 && k == 0 && sl.first_listed);  // (bounce 0's first launch: listed by k_raygen)
       if (l.pre_begin < l.pre_end) {
         scene.lanes_run = lanes_run_of(ctx, l.pre_begin, l.pre_end);
+        scene.fold_run = fold_run_of(ctx, l.pre_begin, l.pre_end);
         launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi,
                        by_spheres ? l.mesh : 0u, by_spheres ? l.mesh + (uint32_t)run : 0u, by_spheres ? sl.worklist : nullptr,
                        sl.tile_desc, sl.tile_stride, by_spheres ? next_epoch(sl) : 0u);
@@ -1569,6 +1585,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     // one pass: trailing spheres + material + stable compaction (decoupled look-back) + final gather
     next_epoch(sl);
     scene.lanes_run = tail ? lanes_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
+    scene.fold_run = tail && !scene.lanes_run ? fold_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
     launch_shade_fused(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, out, sl.hits, ctx->pix_count,
                        ctx->staging(), bounce, last, slot_base_dev, sl.tile_desc, sl.tile_stride, sl.shade_epoch, sl.stage, ctx->band,
                        sl.counters, octs, sl.bi, bounce == 0 && sl.primary_finished ? sl.worklist : nullptr);
@@ -2219,8 +2236,10 @@ int ptc_intersect_rays(ptc_ctx* ctx, const float* rays, uint32_t n, float* hit_t
       int work_slot = 0;
       for (size_t k = 0; k < ctx->launches.size(); ++k) {
         const auto& l = ctx->launches[k];
-        if (l.pre_begin < l.pre_end)
+        if (l.pre_begin < l.pre_end) {
+          scene.fold_run = fold_run_of(ctx, l.pre_begin, l.pre_end);
           launch_spheres(ctx->stream, scene, l.pre_begin, l.pre_end, false, paths, hits, n, 0, counters, bi);
+        }
         scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];
         launch_traverse(ctx->stream, scene, l.mesh, false, paths, hits, 0, work_slot++ % kWorkSlots, counters, false, waves, slow_list,
                         nullptr, ctx->trace_variant, bi);

@@ -220,7 +220,7 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *              frames_in_flight, batch_frames, slot_offset, traverse_waves
  *   SCHEDULE choose between implementations that return the SAME bits; kept for A/B measurements and as cross-checks of
  *            each other, defaults may move with the hardware, a name may go when its alternative goes
- *              fused_shade, filter_rays, merge_instances, sphere_lanes, beam, ray_sort, denoise_variant, bvh_build_on_device,
+ *              fused_shade, filter_rays, merge_instances, sphere_lanes, sphere_fold, beam, ray_sort, denoise_variant, bvh_build_on_device,
  *              layout_on_device, split_idle, refill_lanes, static_eighths, small_waves, small_rays_per_lane, min_waves
  *   TEST     hooks for the parity tests only: debug_lds_entries, debug_force_slow
  * None of them changes a result, with one exception that is the point of it: slot_offset keys the material RNG
@@ -276,6 +276,12 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      lane with the spheres IT cannot rule out ("select approximately, verify exactly": approximate bounds
  *                      on the root the reference would accept, then the reference's own sequence for each candidate);
  *                      0: object by object for the whole wavefront.  Any time
+ *   "sphere_fold"      1 (default): a sphere run IN FRONT of a mesh whose objects are all translated spheres (a room's
+ *                      walls) is walked with the matrix products that are sums with zeros written as those sums, and the hit
+ *                      record's normal finished once, for the hit that remains, instead of for every accepted hit on the way
+ *                      (same operations on the same operands; a wavefront with a ray on one of the exceptions -- a -0.0f
+ *                      coordinate against a zero translation, a zero direction component, anything non-finite -- takes the
+ *                      plain form); 0: the plain form.  Any time
  *   "min_waves"        fewest persistent wavefronts of a traversal launch (default 1024)
  *   "split_idle"       once a traversal launch has handed out its last ray: idle lanes of a persistent wavefront that
  *                      trigger work splitting (an idle lane takes over the bottom of a busy lane's traversal stack

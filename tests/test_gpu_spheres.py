@@ -6,7 +6,13 @@ the oracle's bits: scenes built to sit on the bounds' edges -- a camera inside n
 1e-3 to 1e3 (the subtraction in the discriminant loses the last digits there), coincident spheres (every hit of the pair
 is a tie the LATER object wins, intersections.cuh:30), spheres touching, glass inside glass -- and the runs the per-lane
 form must hand back to the object-by-object form: a scaled sphere (another t unit: transform.hpp:51-58 copies the ray's
-range unscaled), more than eight spheres, spheres in front of a mesh."""
+range unscaled), more than eight spheres, spheres in front of a mesh.
+
+The run IN FRONT of a mesh (k_spheres) has a form of its own for translated spheres, sphere_fold: the reference's sequence
+object by object, with the matrix products that are sums with zeros written as the sums they are and the hit record's
+normal finished once behind the loop.  Its exceptions (a -0.0 coordinate against a zero translation, a direction with a
+zero component, anything not finite) go back to the plain form wavefront by wavefront: the rays of the last test sit on
+exactly those."""
 import numpy as np
 import pytest
 
@@ -74,17 +80,35 @@ def _soup(pkg, kind):
         ball((0.9, 0.1, 0.2), 0.45, "glass")
         ball((0.9, 0.1, 0.2), 0.45, "red")            # coincident again
         ball((-0.9, 0.0, 0.0), 0.5, "steel")
+    elif kind in ("room_mesh", "room_mesh_scaled"):   # a room of wall spheres and balls IN FRONT of a mesh (config 2's shape): sphere_fold
+        big = 1000.0
+        ball((0.0, -big - 1.0, 0.0), big, "white")
+        ball((0.0, 0.0, -big - 2.0), big, "white")
+        ball((-big - 2.0, 0.0, 0.0), big, "red")
+        ball((big + 2.0, 0.0, 0.0), big, "steel")
+        ball((0.0, big + 2.5, 0.0), big, "white")
+        ball((0.0, 0.0, big + 4.0), big, "white")       # behind the camera
+        ball((0.9, -0.5, 0.3), 0.5, "glass")
+        ball((0.9, -0.5, 0.3), 0.25, "water")           # inside the glass ball
+        s.add_object(pkg.Sphere((-1.0, -0.6, 0.2), 0.4), glm.translate((0.0, 0.0, 0.0)), "mirror")   # centre in the sphere, zero translation
+        s.add_object(pkg.Sphere((-1.0, -0.6, 0.2), 0.4), glm.translate((0.0, 0.0, 0.0)), "red")      # coincident: wins every tie
+        if kind == "room_mesh_scaled":                  # one scaled sphere in the run: the whole run takes the plain form
+            ball((0.0, 0.0, 0.0), 1.0, "steel", glm.compose([glm.scale(0.3), glm.translate((0.0, 0.6, -0.5))]))
+        mesh = pkg.scenes.heightfield_mesh(33, 17, 2.0, 1.0, seed=5)
+        s.add_mesh("ground", mesh)
+        s.add_object(mesh, glm.translate((0.0, -0.8, -0.5)), "white")
+        ball((0.0, -0.3, -0.5), 0.3, "glass")           # and a run that ends the list
     return s
 
 
-@pytest.mark.parametrize("kind", ["nested", "overlap", "scaled", "many", "behind_mesh"])
+@pytest.mark.parametrize("kind", ["nested", "overlap", "scaled", "many", "behind_mesh", "room_mesh", "room_mesh_scaled"])
 def test_sphere_runs_against_the_oracle(pkg, orc, kind):
     scene = _soup(pkg, kind)
     flat = scene.build_scene()
     w, h, iters, mb = 96, 64, 3, 12
     ref = orc.render_streaming(flat, scene.camera, w, h, 0, iters, mb)
     got = _frames(pkg, scene, flat, w, h, iters, mb)
-    off = _frames(pkg, scene, flat, w, h, iters, mb, params=(("sphere_lanes", 0),))
+    off = _frames(pkg, scene, flat, w, h, iters, mb, params=(("sphere_lanes", 0), ("sphere_fold", 0)))
     serial = _frames(pkg, scene, flat, w, h, iters, mb, params=(("frames_in_flight", 1),))
     for k in ("color", "normal", "depth"):
         assert np.array_equal(got[k], ref[k]), (kind, k, int(np.sum(got[k] != ref[k])))
@@ -116,3 +140,44 @@ def test_rays_from_inside_and_along_the_surface_of_a_huge_sphere(pkg, orc):
     for k in ("color", "normal", "depth"):
         assert np.array_equal(got[k], ref[k]), (k, int(np.sum(got[k] != ref[k])))
     assert got["rays"] == ref["rays"]
+
+
+def test_rays_on_the_exceptions_of_the_fold(pkg, orc):
+    """ptc_intersect_rays on the room in front of a mesh with rays made for sphere_fold's exceptions: origins with -0.0 and
+    +0.0 coordinates (the walls' translations have two zero components each, the camera of the frame tests sits at x = +0),
+    directions with zero and negative-zero components, origins on a sphere's centre plane (a hit normal with a zero
+    component), rays that start exactly on a wall, huge and tiny t_max."""
+    scene = _soup(pkg, "room_mesh")
+    flat = scene.build_scene()
+    rng = np.random.default_rng(7)
+    n = 16384
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = rng.uniform(-1.8, 1.8, size=(n, 3)).astype(np.float32)
+    rays[:, 1] = rng.uniform(-0.9, 2.3, size=n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 3] = np.where(rng.uniform(size=n) < 0.5, 1e-4, 1e-5)
+    rays[:, 7] = np.where(rng.uniform(size=n) < 0.7, np.finfo(np.float32).max, rng.uniform(0.05, 6.0, size=n))
+    k = np.arange(n)
+    for axis in range(3):
+        rays[k % 7 == axis, axis] = 0.0                   # +0 origin coordinate
+        rays[k % 7 == axis + 3, axis] = -0.0              # -0 origin coordinate
+        rays[k % 11 == axis, 4 + axis] = 0.0              # zero direction component
+        rays[k % 11 == axis + 3, 4 + axis] = -0.0
+    rays[k % 13 == 0, 0:3] = np.float32([-1.0, -0.6, 0.2]) + np.float32([0.0, 0.0, 1.5])     # on the x and y planes of a sphere's centre
+    rays[k % 13 == 0, 4:7] = np.float32([0.0, 0.0, -1.0])
+    rays[k % 17 == 0, 1] = -1.0                           # exactly on the floor sphere's lowest tangent plane... and
+    rays[k % 19 == 0, 0:3] = np.float32([0.9, -0.5, 0.3])  # at the centre of the nested glass balls
+    recs, hit = orc.intersect_rays(flat, rays)
+    for fold in (1, 0):
+        with pkg.PathTracer() as pt:
+            pt.set_param("sphere_fold", fold)
+            pt.create_buffers((64, 64), flat)
+            t, nrm, mat, side = pt.intersect_rays(rays)
+        m = hit.astype(bool)
+        assert 0.5 < m.mean() <= 1.0
+        assert np.array_equal(t >= 0, m), fold
+        assert np.array_equal(t[m].view(np.uint32), recs["t"][m].view(np.uint32)), fold
+        assert np.array_equal(nrm[m].view(np.uint32), recs["normal"][m].view(np.uint32)), fold    # signs of zeros included
+        assert np.array_equal(mat[m], recs["material_id"][m].astype(np.uint32)), fold
+        assert np.array_equal(side[m], recs["side"][m]), fold
