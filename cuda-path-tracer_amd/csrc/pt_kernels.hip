@@ -598,6 +598,88 @@ __device__ __forceinline__ void evaluate_material(f3& ro, f3& rd, bool& tmin_fla
   }
 }
 
+// evaluate_material + the sky of a miss, for a wavefront whose lanes hold DIFFERENT kinds of work (round 4).  From the
+// second bounce on the 64 paths of a wavefront have scattered: in the Cornell-box scenes most wavefronts hold diffuse,
+// metal and glass hits and a path that left the box, and a `switch` over the kinds executes its four bodies one after
+// the other -- 530 VALU instructions where a diffuse-only wavefront needs 205 (profiles/r04_config2_counters.txt).
+// The bodies are made of the same few expensive pieces -- two draws, normalize, sqrt(1 - c^2), the sine / cosine -- on
+// different operands.  This form runs every piece ONCE, each lane with the operands of its own kind, in an order that
+// every kind can follow:
+//     draws (all hits; the second one diffuse and metal)
+//     A  unit = normalize(rd)                                   glass, miss
+//     B  sin = sqrt(1 - cos^2), cos = 2 u2 - 1 | min(-unit.n, 1)  diffuse, metal | glass
+//     .  sine / cosine of phi, the point on the unit sphere     diffuse, metal
+//     C  sqrt(|n + r|^2) | sqrt(k)                              diffuse (then 1 / it) | glass that refracts
+//     the kinds' own few operations
+// A lane executes exactly the operations of its kind's body in evaluate_material / background, on the same operands:
+// the same bits (the frames tests compare this kernel with k_shade's plain form and with the oracle).
+// kind: 0 diffuse, 1 metal, 2 dielectric (Material::type), 3 miss, anything else: nothing to do.
+__device__ __forceinline__ void shade_kinds(const uint32_t kind, f3& ro, f3& rd, bool& tmin_flag, const f3 hp, const f3 hn,
+                                            const uint32_t side, const DMaterial m, const uint32_t slot, const uint32_t iteration,
+                                            const uint32_t bounce, f3& color)
+{
+  float u1 = 0.0f, u2 = 0.0f;
+  if (kind <= 2u) {
+    Minstd rng;
+    rng.seed(path_seed(slot, iteration));  // re-seeded from the global slot index, then discard(bounce) (path_tracer.cu:300-301)
+    rng.discard(bounce);
+    u1 = rng.uniform();
+    if (kind <= 1u) u2 = rng.uniform();
+  }
+  if (kind <= 1u) ro = hp - hn * (1e-4f * sign_of(dot(rd, hn)));
+  f3 unit = rd;
+  if (kind == 2u || kind == 3u) unit = normalize(rd);
+  float cos_theta = 0.0f, sin_theta = 0.0f;
+  if (kind <= 2u) {
+    cos_theta = kind <= 1u ? 2.f * u2 - 1.f : sel_min(dot(-unit, hn), 1.0f);
+    sin_theta = ieee_sqrt(1.0f - cos_theta * cos_theta);
+  }
+  f3 r = mk3(0.f, 0.f, 0.f);  // random_on_unit_sphere
+  if (kind <= 1u) {
+    const float phi = 2.f * 3.14159265358979323846264338327950288f * u1;
+    float sn, cs;
+    det_sincos(phi, sn, cs);
+    r = mk3(cs * sin_theta, sn * sin_theta, cos_theta);
+  }
+  const f3 v = hn + r;  // diffuse
+  float root_of = dot(v, v);
+  float ratio = 1.0f, dv = 0.0f, k = 0.0f;
+  bool reflects = false;
+  if (kind == 2u) {
+    const float ior = m.p[0];
+    ratio = side == 0u ? (1.0f / ior) : ior;
+    const bool cannot_refract = ratio * sin_theta > 1.0f;
+    reflects = cannot_refract || schlick(cos_theta, ratio) > u1;  // (the draw is the path's first either way)
+    dv = dot(hn, unit);
+    k = 1.0f - ratio * ratio * (1.0f - dv * dv);
+    root_of = k;
+  }
+  float root = 0.0f;
+  if (kind == 0u || (kind == 2u && !reflects)) root = ieee_sqrt(root_of);
+  if (kind == 0u) {
+    f3 dir = v * (1.0f / root);
+    if (fabs((double)dir.x) < 1e-8 && fabs((double)dir.y) < 1e-8 && fabs((double)dir.z) < 1e-8) dir = hn;
+    rd = dir;
+    color = color * mk3(m.p[0], m.p[1], m.p[2]);
+  } else if (kind == 1u) {
+    const f3 reflected = rd - (hn * dot(hn, rd)) * 2.0f;
+    const f3 dir = reflected + r * m.p[3];
+    rd = dir;
+    if (dot(dir, hn) > 0.0f) color = color * mk3(m.p[0], m.p[1], m.p[2]);
+    else color = mk3(0.0f, 0.0f, 0.0f);
+  } else if (kind == 2u) {
+    f3 dir;
+    if (reflects) dir = unit - (hn * dot(hn, unit)) * 2.0f;
+    else dir = (k >= 0.0f) ? (unit * ratio - hn * (ratio * dv + root)) : mk3(0.0f, 0.0f, 0.0f);
+    ro = hp;
+    rd = dir;
+    tmin_flag = true;
+  } else if (kind == 3u) {
+    const float t = 0.5f * (unit.y + 1.0f);  // background(), path_tracer.cu:29-34
+    color = color * (mk3(0.5f, 0.7f, 1.0f) * (1.0f - t) + mk3(1.0f, 1.0f, 1.0f) * t);
+  }
+}
+
 // final_gather, path_tracer.cu:203-219
 __device__ __forceinline__ float running_mean(uint32_t iteration, float old_v, float new_v)
 {
@@ -889,6 +971,12 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 #ifndef PT_SPHERE_LANES
 #define PT_SPHERE_LANES 1
 #endif
+#ifndef PT_REGION_BLOCKS
+#define PT_REGION_BLOCKS 1
+#endif
+#ifndef PT_SHADE_KINDS
+#define PT_SHADE_KINDS 1
+#endif
 #ifndef PT_FOLD_TAIL
 #define PT_FOLD_TAIL 0
 #endif
@@ -1028,7 +1116,8 @@ __device__ __forceinline__ void sphere_segment(const DScene& sc, uint32_t obj_be
 // In front of a mesh the spheres are typically a room's walls: every ray is inside every one of them, every wall is hit,
 // and which one wins is decided only by distance -- there is nothing to rule out, so sphere_segment pays the whole
 // sequence of path_tracer.cu:84-96 + intersections.cuh:7-41 for every object (226 VALU instructions per ray and sphere
-// on the Cornell box, five walls: the launch ran at 79 % VALU issue, profiles/r04_config2_counters.txt).  When every
+// on the Cornell box's walls, behind four dependent vector loads of the object's data: 1.15 ms per 29.5 M rays at 39 % of the VALU
+// issue rate and 1.8 TB/s -- bound by neither, by its chains of dependent operations; profiles/r04_config2_counters.txt).  When every
 // object of the run is "simple" (DScene::fold_run: both matrices pure translations, 3 x 3 part 1.0f / +-0.0f) the same
 // operations on the same operands come much cheaper:
 //   * transform_point's row (1 x + e y) + (e' z + t 1), e, e' zeros of either sign, IS x + t: the products with the
@@ -1349,18 +1438,57 @@ struct BatchFeed {
   uint32_t stride, count, bounce, work_slot, static_eighths, dyn_batch;
   bool listed;  // the launch walks a work list (DeviceCounters::list_count entries per frame, read through `order`), not all live rays
   __device__ __forceinline__ uint32_t rays_of(uint32_t f) const { return listed ? ctr[f].list_count : ctr[f].live[bounce]; }
-  uint32_t home_f, home_r, home_base, stat_next, stat_step, stat_count;
+  uint32_t home_f, home_r, home_base, home_rs, stat_next, stat_step, stat_count;
   bool in_static, done;
 
+#if PT_REGION_BLOCKS
+  // The eight regions of a frame's rays are INTERLEAVED (round 4): the rays, in slot / list order, are cut into blocks of
+  // B batches of 64, and block j belongs to region j mod 8; a region walks its blocks in order.  Every region then holds
+  // the same mix of the image, top to bottom -- with contiguous eighths the most expensive eighth of a primary-ray
+  // launch (the rows at the horizon) was the last to run dry, the last rays fetched were the launch's longest, and
+  // the launch ended 570 us after its feed (profiles/r04_tail_bounce0.txt); now the last rays of every region are
+  // the image's bottom rows.  B = 256 batches (eight image rows) when the frame has that many, fewer for a small frame
+  // so that every region still gets eight blocks; a power of two >= 2, so a dynamic batch of 128 rays never straddles
+  // a block.  A region-local ray offset is mapped to its position in the frame's order by pos_of.
+  static __device__ __forceinline__ uint32_t block_batches_of(uint32_t n)
+  {
+    const uint32_t want = ((n + kWave - 1u) / kWave) / 64u;  // batches / (8 regions x 8 blocks)
+    uint32_t b = 2u;
+    while (b < 256u && 2u * b <= want) b *= 2u;
+    return b;
+  }
+  static __device__ __forceinline__ uint32_t region_len_of(uint32_t n, uint32_t bb, uint32_t r)
+  {
+    const uint32_t nb = (n + kWave - 1u) / kWave;  // batches of the frame
+    if (nb == 0u) return 0u;
+    const uint32_t nblk = (nb + bb - 1u) / bb;
+    if (r >= nblk) return 0u;
+    uint32_t batches = ((nblk - r + 7u) / 8u) * bb;
+    const uint32_t last_blk = nblk - 1u;
+    if ((last_blk & 7u) == r) {
+      batches -= bb - (nb - last_blk * bb);           // the frame's last block may be short
+      return batches * kWave - (nb * kWave - n);      // ... and its last batch
+    }
+    return batches * kWave;
+  }
+  static __device__ __forceinline__ uint32_t pos_of(uint32_t bb, uint32_t r, uint32_t local)
+  {
+    const uint32_t k = local / kWave;
+    return (((k / bb) * 8u + r) * bb + k % bb) * kWave + local % kWave;
+  }
+  static __device__ __forceinline__ uint32_t region_size_of(uint32_t n) { return block_batches_of(n); }
+#else
   static __device__ __forceinline__ uint32_t region_size_of(uint32_t n) { return ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave; }
   static __device__ __forceinline__ uint32_t region_len_of(uint32_t n, uint32_t rs, uint32_t r)
   {
     const uint32_t b = r * rs;
     return b < n ? min(n - b, rs) : 0u;
   }
+  static __device__ __forceinline__ uint32_t pos_of(uint32_t rs, uint32_t r, uint32_t local) { return r * rs + local; }
+#endif
   __device__ __forceinline__ uint32_t static_batches_of(uint32_t len) const
   {
-    return ((len + kWave - 1u) / kWave) * static_eighths / 8u;
+    return (((len + kWave - 1u) / kWave) * static_eighths / 8u) & ~1u;  // (even: a dynamic batch of two starts on an even batch)
   }
   __device__ __forceinline__ void init(DeviceCounters* ctr_, const DBatchInfo& bi, int bounce_, int work_slot_,
                                        uint32_t static_eighths_, bool listed_ = false)
@@ -1380,14 +1508,16 @@ struct BatchFeed {
     stat_step = (with_r - home_f + count - 1u) / count;      // ... of which this many share the home
     stat_next = j / count;
     const uint32_t n = rays_of(home_f);
-    const uint32_t rs = region_size_of(n);
-    stat_count = static_batches_of(region_len_of(n, rs, home_r));
-    home_base = home_f * stride + home_r * rs;
+    home_rs = region_size_of(n);
+    stat_count = static_batches_of(region_len_of(n, home_rs, home_r));
+    home_base = home_f * stride;
     in_static = static_eighths != 0u;
     done = false;
     // dynamic batches: one atomic hands out this many rays (a cursor line sustains ~30 atomics/us)
     // (re-measured on round 3's final build: 64 everywhere -6 %, 256 or other thresholds within noise)
-    dyn_batch = (uint64_t)n * count / gridDim.x >= 256u ? 128u : (uint32_t)kWave;
+    // (the same for every wavefront of the launch -- frame 0's count decides: the cursors then only ever stand on multiples
+    // of it, and a batch of two never straddles two blocks of a region)
+    dyn_batch = (uint64_t)rays_of(0u) * count / gridDim.x >= 256u ? 128u : (uint32_t)kWave;
   }
   __device__ __forceinline__ bool exhausted() const { return !in_static && done; }
   // wave-uniform: next batch [begin, end) of batch-global slots, or false
@@ -1395,7 +1525,7 @@ struct BatchFeed {
   {
     if (in_static) {
       if (stat_next < stat_count) {
-        begin = home_base + stat_next * kWave;
+        begin = home_base + pos_of(home_rs, home_r, stat_next * kWave);
         end = begin + kWave;  // static batches are full batches inside the region
         stat_next += stat_step;
         return true;
@@ -1407,18 +1537,23 @@ struct BatchFeed {
       for (uint32_t first_p = 0u; first_p < 8u * count; first_p += (uint32_t)kWave) {
         const uint32_t p = first_p + threadIdx.x;
         bool has = false;
-        uint32_t len = 0u, first = 0u, gbase = 0u;
+        uint32_t len = 0u, first = 0u, gbase = 0u, grs = 0u, gr = 0u;
         uint32_t* cursor = nullptr;
         if (p < 8u * count) {
           const uint32_t df = p % count, dr = p / count;
           uint32_t f = home_f + df;
           if (f >= count) f -= count;
+          // (own region first, then the next ones in turn.  Every wavefront walking the regions in the same order -- so that
+          // the launch ends on a chosen one -- was measured: the end of a primary-ray launch 300 instead of 570 us after its
+          // feed, the launch as a whole 2 % LONGER, the later bounces 5-20 %: twenty cursors for 5120 wavefronts.)
           const uint32_t r = (home_r + dr) & 7u;
           const uint32_t n = rays_of(f);
           const uint32_t rs = region_size_of(n);
           len = region_len_of(n, rs, r);
           first = static_batches_of(len) * kWave;
-          gbase = f * stride + r * rs;
+          gbase = f * stride;
+          grs = rs;
+          gr = r;
           cursor = &ctr[f].work[work_slot][r][0];
           has = first < len && first + __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len;
         }
@@ -1432,8 +1567,9 @@ struct BatchFeed {
         const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, sel);
         const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gbase, sel);
         if (b < l) {
-          begin = g + b;
-          end = g + min(l, b + dyn_batch);
+          const uint32_t rs_sel = (uint32_t)__builtin_amdgcn_readlane((int)grs, sel), r_sel = (uint32_t)__builtin_amdgcn_readlane((int)gr, sel);
+          begin = g + pos_of(rs_sel, r_sel, b);
+          end = begin + (min(l, b + dyn_batch) - b);
           return true;
         }
         break;  // another wavefront took the rest of that region: look again
@@ -2674,6 +2810,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       const uint32_t pixel = pixbits & 0x7fffffffu;
       const uint32_t local_pixel = band_local(band, pixel);
       bool tmin_flag = (pixbits >> 31) != 0u;
+#if PT_SHADE_KINDS
+      const bool is_hit = (hit_mask >> j & 1u) != 0u;
+      const f3 hn = xyz(nm[j]);
+      const uint32_t ms = __float_as_uint(nm[j].w);
+      DMaterial m{3, {0.f, 0.f, 0.f, 0.f}};  // (types are 0..2: validate_scene)
+      if (is_hit) m = sc.materials[ms & 0x7fffffffu];
+      if (bounce == 0) {
+        if (is_hit) accumulate_nd(fb.nd4, local_pixel, acc_iteration, hn, tp[j].x);  // path_tracer.cu:308-311
+        else accumulate_nd(fb.nd4, local_pixel, acc_iteration, -rd, 1e6f);           // raygen defaults, ray_gen.cu:26-28
+      }
+      const uint32_t slot = (slot_base ? *slot_base : 0u) + s;
+      shade_kinds((uint32_t)m.type, ro, rd, tmin_flag, mk3(tp[j].y, tp[j].z, tp[j].w), hn, ms >> 31, m, slot, iteration, (uint32_t)bounce, color);
+      if (!is_hit || last_bounce) {
+        // a miss ends the path with throughput * sky (path_tracer.cu:304-307, 283-289); capped paths deposit raw throughput
+        accumulate_color(fb.color4, local_pixel, acc_iteration, color);
+      } else {
+        surv_mask |= 1u << j;
+        o4[j] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixel | (tmin_flag ? 0x80000000u : 0u)));
+        d4[j] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        t4[j] = make_float4(color.x, color.y, color.z, 0.0f);
+      }
+#else
       if (!(hit_mask >> j & 1u)) {
         // miss: throughput *= sky; the path ends (path_tracer.cu:304-307, 283-289)
         color = color * background(rd);
@@ -2700,6 +2858,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
           t4[j] = make_float4(color.x, color.y, color.z, 0.0f);
         }
       }
+#endif
     }
   }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--fif", type=int, default=0, help="frames in flight (0 = --frames: one batch)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--param", action="append", default=[])
+    ap.add_argument("--by-xcd", action="store_true", help="per XCD (workgroup id mod 8): when its wavefronts ran out of rays and left")
     ap.add_argument("--repeat", type=int, default=3, help="batches traced before the one that is read")
     args = ap.parse_args()
     pkg = graft.load_package()
@@ -86,6 +87,13 @@ def main():
               f" {np.percentile(tail_it[ok], 50):5.0f} {np.percentile(tail_it[ok], 90):5.0f} {tail_it[ok].max():5d} |"
               f" {np.nansum(exh - start) / max(iters_exh[ok].sum(), 1):5.2f} {np.nansum(own) / max(tail_it[ok].sum(), 1):5.2f} |"
               f" {np.percentile(lanes_exh[ok], 50):3.0f} | {(splits > 0).sum():6d}   late starts (>5us): {(start > 5).sum()}")
+        if args.by_xcd:
+            blk = np.nonzero(ran)[0]
+            for x in range(8):
+                m = (blk % 8) == x
+                print(f"        xcd {x}: waves {m.sum():5d}  exhaustion p10 {np.nanpercentile(exh[m], 10):7.1f} p50 {np.nanpercentile(exh[m], 50):7.1f} p90 {np.nanpercentile(exh[m], 90):7.1f}"
+                      f" | exit p50 {np.percentile(end[m], 50):7.1f} p90 {np.percentile(end[m], 90):7.1f} last {end[m].max():7.1f} | iterations mean {iters[m].mean():7.1f} | tail iterations p50 {np.percentile(tail_it[m & ok], 50):4.0f}"
+                      f" | us per tail iteration {np.nansum(own[m]) / max(tail_it[m & ok].sum(), 1):5.2f}")
         ti = max(int(tail_it[ok].sum()), 1)
         print(f"        shader-clock cycles per tail iteration: retire {r[ok, 4].sum() / ti:7.0f}  split {r[ok, 5].sum() / ti:7.0f}  step {r[ok, 6].sum() / ti:7.0f}"
               f"   active lanes per tail iteration {(r[ok, 7] & np.uint64(0xffffff)).sum() / ti:5.1f}"
