@@ -206,6 +206,7 @@ struct DFrame {
 
 struct DeviceCounters {
   uint32_t live[kMaxBounces + 1];  // live paths entering bounce b of the current frame
+  uint32_t listed_now[kMaxBounces + 1];  // rays on the work list of bounce b's (last) listed traversal launch; with live[]: what the host sizes later launches by
   uint32_t flags;
   uint32_t slow_count;             // rays set aside for the exact redo by the running traversal launch
   uint32_t waves_done;             // wavefronts of the running traversal launch that have signed off

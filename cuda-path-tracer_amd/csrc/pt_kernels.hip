@@ -1646,6 +1646,7 @@ __device__ __forceinline__ void launch_epilogue(DeviceCounters* counters, int bo
     for (uint32_t f = threadIdx.x; f < bi.count; f += (uint32_t)kWave) listed += counters[f].list_count;
   listed = wave_sum(listed);
   if (threadIdx.x == 0u) {
+    if (was_listed) counters->listed_now[bounce] = counters->list_count;
     counters->listed_rays[bounce] += listed;
     counters->slow_rays[bounce] += redone;
     counters->slow_count = 0u;

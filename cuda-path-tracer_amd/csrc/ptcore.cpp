@@ -199,7 +199,7 @@ struct ptc_ctx {
                                       // per lane -- are 12-14 % faster on all 5120 wavefronts than on 3072)
   // live paths entering each bounce of one recent frame (what a frame of this scene / camera looks like): the host
   // never waits for them, they only size the traversal launches
-  uint32_t est_live[kMaxBounces + 1] = {};
+  uint32_t est_live[2 * (kMaxBounces + 1)] = {};  // live[], then listed_now[] (DeviceCounters) of a recent batch's first frame
   bool est_valid = false;
   bool filter_rays = true;    // "filter_rays": a sphere run in front of a mesh launch also lists the rays that launch has to walk
   bool fused_shade = true;    // "fused_shade": the end of a bounce in one pass (k_shade_fused); 0: k_tail_count -> k_scan -> k_shade
@@ -1057,7 +1057,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
       sl.own_stream = true;
     }
     HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.live_host), sizeof(uint32_t) * (kMaxBounces + 1), hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.live_host), sizeof(uint32_t) * 2 * (kMaxBounces + 1), hipHostMallocDefault));
     const size_t BP = (size_t)B * P;  // frame f of the batch at element offset f * P (DBatchInfo::stride)
     for (int k = 0; k < 2; ++k) {
       if (int rc = dev_alloc(ctx, pool, &sl.paths[k].o4, BP)) return rc;
@@ -1364,7 +1364,7 @@ uint32_t next_epoch(ptc_ctx::FrameSlot& sl)
   return sl.shade_epoch;
 }
 
-uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce)
+uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce, bool listed)
 {
   for (auto& sl : ctx->slots)
     if (sl.live_pending && sl.done && hipEventQuery(sl.done) == hipSuccess) {
@@ -1375,6 +1375,10 @@ uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce)
   (void)hipGetLastError();  // hipEventQuery's "not ready" is no error
   uint64_t per_frame = ctx->pix_count;
   if (ctx->est_valid && ctx->est_live[0] == ctx->pix_count) per_frame = std::min<uint64_t>(ctx->pix_count, ctx->est_live[bounce]);
+  // a launch that walks a work list carries the listed rays only (a single frame's primary rays: 0.85 of 2.07 M on the
+  // benchmark scene -- 2.6 rays per lane of a full launch, and the smaller launch ends sooner)
+  if (listed && ctx->est_valid && ctx->est_live[0] == ctx->pix_count && ctx->est_live[kMaxBounces + 1 + bounce] != 0u)
+    per_frame = std::min<uint64_t>(per_frame, (uint64_t)ctx->est_live[kMaxBounces + 1 + bounce] * 9u / 8u + 64u);
   const uint64_t rays = per_frame * frames;
   // (fewer than four rays per lane at full size: 3072 wavefronts do as well or a little better -- single frames)
   const uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * ctx->small_rays_per_lane ? ctx->traverse_waves
@@ -1555,7 +1559,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       }
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
       if (int rc = timed_begin(tl)) return rc;
-      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce);
+      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce, listed);
       scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
       const uint32_t* pick = listed ? sl.worklist : (sorted ? sl.order : nullptr);
       if (run > 1) {
@@ -1615,7 +1619,7 @@ int batch_end(ptc_ctx* ctx)
   }
   // the live counts of this batch's first frame, for the sizing of later launches (nobody waits for the copy)
   if (sl.live_host && sl.bounces_done == ctx->max_bounces) {
-    HIP_TRY(ctx, hipMemcpyAsync(sl.live_host, &sl.counters[0].live[0], sizeof(uint32_t) * (kMaxBounces + 1), hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sl.live_host, &sl.counters[0].live[0], sizeof(uint32_t) * 2 * (kMaxBounces + 1), hipMemcpyDeviceToHost, sl.stream));
     sl.live_pending = true;
   }
   HIP_TRY(ctx, hipEventRecord(sl.done, sl.stream));
