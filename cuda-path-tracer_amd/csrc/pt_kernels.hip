@@ -21,6 +21,7 @@
 #include "pt_device.hpp"
 #include "pt_rng.hpp"
 #include "pt_beam_rules.hpp"
+#include "pt_feed_rules.hpp"
 
 #include <float.h>
 
@@ -971,9 +972,6 @@ __global__ __launch_bounds__(kWave) void k_trace_wide(DScene sc, DPaths paths, D
 #ifndef PT_SPHERE_LANES
 #define PT_SPHERE_LANES 1
 #endif
-#ifndef PT_REGION_BLOCKS
-#define PT_REGION_BLOCKS 1
-#endif
 #ifndef PT_SHADE_KINDS
 #define PT_SHADE_KINDS 1
 #endif
@@ -1441,54 +1439,13 @@ struct BatchFeed {
   uint32_t home_f, home_r, home_base, home_rs, stat_next, stat_step, stat_count;
   bool in_static, done;
 
-#if PT_REGION_BLOCKS
-  // The eight regions of a frame's rays are INTERLEAVED (round 4): the rays, in slot / list order, are cut into blocks of
-  // B batches of 64, and block j belongs to region j mod 8; a region walks its blocks in order.  Every region then holds
-  // the same mix of the image, top to bottom -- with contiguous eighths the most expensive eighth of a primary-ray
-  // launch (the rows at the horizon) was the last to run dry, the last rays fetched were the launch's longest, and
-  // the launch ended 570 us after its feed (profiles/r04_tail_bounce0.txt); now the last rays of every region are
-  // the image's bottom rows.  B = 256 batches (eight image rows) when the frame has that many, fewer for a small frame
-  // so that every region still gets eight blocks; a power of two >= 2, so a dynamic batch of 128 rays never straddles
-  // a block.  A region-local ray offset is mapped to its position in the frame's order by pos_of.
-  static __device__ __forceinline__ uint32_t block_batches_of(uint32_t n)
-  {
-    const uint32_t want = ((n + kWave - 1u) / kWave) / 64u;  // batches / (8 regions x 8 blocks)
-    uint32_t b = 2u;
-    while (b < 256u && 2u * b <= want) b *= 2u;
-    return b;
-  }
-  static __device__ __forceinline__ uint32_t region_len_of(uint32_t n, uint32_t bb, uint32_t r)
-  {
-    const uint32_t nb = (n + kWave - 1u) / kWave;  // batches of the frame
-    if (nb == 0u) return 0u;
-    const uint32_t nblk = (nb + bb - 1u) / bb;
-    if (r >= nblk) return 0u;
-    uint32_t batches = ((nblk - r + 7u) / 8u) * bb;
-    const uint32_t last_blk = nblk - 1u;
-    if ((last_blk & 7u) == r) {
-      batches -= bb - (nb - last_blk * bb);           // the frame's last block may be short
-      return batches * kWave - (nb * kWave - n);      // ... and its last batch
-    }
-    return batches * kWave;
-  }
-  static __device__ __forceinline__ uint32_t pos_of(uint32_t bb, uint32_t r, uint32_t local)
-  {
-    const uint32_t k = local / kWave;
-    return (((k / bb) * 8u + r) * bb + k % bb) * kWave + local % kWave;
-  }
-  static __device__ __forceinline__ uint32_t region_size_of(uint32_t n) { return block_batches_of(n); }
-#else
-  static __device__ __forceinline__ uint32_t region_size_of(uint32_t n) { return ((n + 8u * kWave - 1u) / (8u * kWave)) * kWave; }
-  static __device__ __forceinline__ uint32_t region_len_of(uint32_t n, uint32_t rs, uint32_t r)
-  {
-    const uint32_t b = r * rs;
-    return b < n ? min(n - b, rs) : 0u;
-  }
-  static __device__ __forceinline__ uint32_t pos_of(uint32_t rs, uint32_t r, uint32_t local) { return r * rs + local; }
-#endif
+  // (the regions' geometry: pt_feed_rules.hpp, shared with the host's check, ptc_check_feed)
+  static __device__ __forceinline__ uint32_t region_size_of(uint32_t n) { return feed_rules::region_size_of(n); }
+  static __device__ __forceinline__ uint32_t region_len_of(uint32_t n, uint32_t rs, uint32_t r) { return feed_rules::region_len_of(n, rs, r); }
+  static __device__ __forceinline__ uint32_t pos_of(uint32_t rs, uint32_t r, uint32_t local) { return feed_rules::pos_of(rs, r, local); }
   __device__ __forceinline__ uint32_t static_batches_of(uint32_t len) const
   {
-    return (((len + kWave - 1u) / kWave) * static_eighths / 8u) & ~1u;  // (even: a dynamic batch of two starts on an even batch)
+    return feed_rules::static_batches_of(len, static_eighths);
   }
   __device__ __forceinline__ void init(DeviceCounters* ctr_, const DBatchInfo& bi, int bounce_, int work_slot_,
                                        uint32_t static_eighths_, bool listed_ = false)

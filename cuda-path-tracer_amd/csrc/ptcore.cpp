@@ -27,6 +27,7 @@
 #include "pt_device.hpp"
 #include "pt_host.hpp"
 #include "pt_beam_rules.hpp"
+#include "pt_feed_rules.hpp"
 
 using namespace pt;
 
@@ -2440,6 +2441,47 @@ int ptc_check_beam(const float* positions, uint32_t vertex_count, const uint32_t
     stats5[3] = rays;
     stats5[4] = hits;
   }
+  return bad;
+}
+
+// The ray feed of the persistent traversal launches (BatchFeed; pt_feed_rules.hpp) checked on the host: a frame of n rays,
+// its eight regions, each dealt as static_eighths / 8 static batches of 64 followed by dynamic batches of dyn_batch (64 or
+// 128) rays.  Every ray of the frame must be handed out exactly once, every batch must be contiguous in the frame's order
+// and inside the frame.  Returns the number of violations (0 = sound) or a negative status.
+int ptc_check_feed(uint32_t n, uint32_t static_eighths, uint32_t dyn_batch)
+{
+  if (static_eighths > 8u || (dyn_batch != 64u && dyn_batch != 128u) || n > (1u << 28)) return PTC_ERR_INVALID;
+  std::vector<uint8_t> seen(n, 0);
+  int bad = 0;
+  auto hand_out = [&](uint32_t begin, uint32_t end) {
+    if (end > n || begin >= end) { ++bad; return; }
+    for (uint32_t q = begin; q < end; ++q) {
+      if (seen[q]) ++bad;
+      seen[q] = 1;
+    }
+  };
+  const uint32_t rs = feed_rules::region_size_of(n);
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < 8u; ++r) {
+    const uint32_t len = feed_rules::region_len_of(n, rs, r);
+    total += len;
+    const uint32_t stat = feed_rules::static_batches_of(len, static_eighths);
+    if ((uint64_t)stat * 64u > len) { ++bad; continue; }
+    for (uint32_t k = 0; k < stat; ++k) {  // BatchFeed::acquire, static part: full batches
+      const uint32_t begin = feed_rules::pos_of(rs, r, k * 64u);
+      hand_out(begin, begin + 64u);
+    }
+    for (uint32_t b = stat * 64u; b < len; b += dyn_batch) {  // ... dynamic part: the cursor advances by dyn_batch
+      const uint32_t begin = feed_rules::pos_of(rs, r, b);
+      const uint32_t count = std::min(len, b + dyn_batch) - b;
+      hand_out(begin, begin + count);
+      // a batch of two must be contiguous: its second half where the map puts it
+      if (count > 64u && feed_rules::pos_of(rs, r, b + 64u) != begin + 64u) ++bad;
+    }
+  }
+  if (total != n) ++bad;
+  for (uint32_t q = 0; q < n; ++q)
+    if (!seen[q]) ++bad;
   return bad;
 }
 

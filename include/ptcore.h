@@ -425,6 +425,11 @@ int ptc_make_object(uint32_t type, uint32_t index, const float* m16, const ptc_s
  * violations (0 = sound), or a negative ptc_status; *checked_boxes (may be NULL) gets the number of child boxes
  * looked at. */
 int ptc_check_traversal_layout(const ptc_bvh_node* nodes, uint32_t node_count, uint64_t* checked_boxes);
+/* The ray feed of the persistent traversal launches, checked on the host (no GPU; test hook): a frame of n rays dealt in
+ * eight regions, static_eighths / 8 of every region as static batches of 64, the rest as dynamic batches of dyn_batch (64
+ * or 128) rays, with the region geometry the kernels use (csrc/pt_feed_rules.hpp).  Returns the number of rays handed out
+ * twice or never and of batches that are not contiguous or leave the frame (0 = sound), or a negative ptc_status. */
+int ptc_check_feed(uint32_t n, uint32_t static_eighths, uint32_t dyn_batch);
 /* Entry points for primary rays ("beam"), checked on the host (no GPU): for every 8 x 8-pixel tile of a width x height
  * frame of `camera`, the entries k_beam computes for the mesh under the object matrix object_m16 (NULL: identity;
  * column-major), and for sample rays of the tile (corners and centre of the jitter range of every stride-th pixel) the

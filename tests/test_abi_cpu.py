@@ -218,3 +218,21 @@ def test_entry_points_of_primary_rays_are_sound(pkg):
     # the case that looks away keeps nothing at all
     _, st = _beam_check(pkg, hf, look((0.0, 2.0, 6.0), (0.0, 3.0, 12.0), vfov_deg=50.0), 64, 40)
     assert st[1] == st[0] and st[4] == 0
+
+
+def test_the_ray_feed_hands_every_ray_out_once(pkg):
+    """ptc_check_feed (host, no GPU): the geometry of the traversal launches' ray feed (csrc/pt_feed_rules.hpp: eight
+    regions of interleaved blocks, static batches then dynamic ones) on frame sizes around every boundary it has -- a
+    batch, a block, eight blocks, the benchmark's per-bounce live counts -- for every static share and both dynamic batch
+    sizes.  Found the hard way in round 4: a batch of two that straddled two blocks traced 64 rays of another region
+    twice and skipped 64 of its own; only the 643 M-ray soak test noticed."""
+    lib = pkg.lib()
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1024, 1025, 8191, 8192, 8193, 16383, 16384, 16385,
+             65097, 65536, 89175, 126854, 131072, 131073, 183471, 281220, 425894, 769669, 924531, 2073600]
+    sizes += [int(x) for x in rng.integers(1, 3_000_000, size=24)]
+    for n in sizes:
+        for eighths in (0, 1, 3, 7, 8):
+            for dyn in (64, 128):
+                assert lib.ptc_check_feed(n, eighths, dyn) == 0, (n, eighths, dyn)
+    assert lib.ptc_check_feed(100, 9, 64) < 0 and lib.ptc_check_feed(100, 3, 96) < 0
