@@ -181,3 +181,35 @@ def test_rays_on_the_exceptions_of_the_fold(pkg, orc):
         assert np.array_equal(nrm[m].view(np.uint32), recs["normal"][m].view(np.uint32)), fold    # signs of zeros included
         assert np.array_equal(mat[m], recs["material_id"][m].astype(np.uint32)), fold
         assert np.array_equal(side[m], recs["side"][m]), fold
+
+
+def test_scaled_instances_behind_closer_spheres(pkg, orc):
+    """The work list the sphere kernel builds for the mesh launch behind it drops a ray whose instance boxes all START beyond
+    the closest hit so far.  That is a comparison of world distances, and it is right for a mesh of any scale because the
+    reference tests a mesh's triangles in WORLD space (path_tracer.cu:57-62: transform_point on the three vertices, the world
+    ray) -- only a sphere's root is compared in object space (transform.hpp:51-58).  Pinned here: small spheres in front of
+    a three-fold and a 0.4-fold instance, with the filter and without it, against the oracle."""
+    glm = pkg.glmlite
+    s = pkg.SceneDescription()
+    s.resolution = (128, 64)
+    s.camera = pkg.Camera(position=(0.0, 0.5, 4.0), rotation=(1.0, 0.0, 0.0, 0.0), vfov=float(np.radians(45)))
+    s.add_material("white", pkg.DiffuseMateral((0.8, 0.8, 0.8)))
+    s.add_material("red", pkg.DiffuseMateral((0.8, 0.2, 0.2)))
+    s.add_material("steel", pkg.MetalMaterial((0.8, 0.8, 0.9), 0.1))
+    s.add_object(pkg.Sphere((0, 0, 0), 0.35), glm.translate((-0.9, 0.45, 1.5)), "red")     # in front of the big instance
+    s.add_object(pkg.Sphere((0, 0, 0), 0.35), glm.translate((0.9, 0.45, 1.5)), "steel")    # in front of the small one
+    s.add_object(pkg.Sphere((0, 0, 0), 0.2), glm.translate((0.0, 0.2, 2.5)), "red")
+    mesh = pkg.scenes.heightfield_mesh(33, 17, 1.0, 0.5, seed=9)
+    s.add_mesh("ground", mesh)
+    s.add_object(mesh, glm.compose([glm.scale(3.0), glm.translate((-1.2, -0.2, -1.5))]), "white")
+    s.add_object(mesh, glm.compose([glm.scale(0.4), glm.translate((1.0, 0.0, 0.6))]), "white")
+    s.add_object(pkg.Sphere((0, 0, 0), 0.25), glm.translate((0.0, 0.9, 0.0)), "steel")     # a run that ends the list
+    flat = s.build_scene()
+    w, h, iters, mb = 128, 64, 3, 8
+    ref = orc.render_streaming(flat, s.camera, w, h, 0, iters, mb)
+    got = _frames(pkg, s, flat, w, h, iters, mb)
+    plain = _frames(pkg, s, flat, w, h, iters, mb, params=(("filter_rays", 0),))
+    for k in ("color", "normal", "depth"):
+        assert np.array_equal(plain[k], ref[k]), (k, "filter_rays 0", int(np.sum(plain[k] != ref[k])))
+        assert np.array_equal(got[k], ref[k]), (k, int(np.sum(got[k] != ref[k])))
+    assert got["rays"] == ref["rays"]
