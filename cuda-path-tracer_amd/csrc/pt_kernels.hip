@@ -2583,13 +2583,19 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 //     kFlagDispatchOrder and ptc_get_stats reports an error instead of an image;
 //   * descriptors carry the launch's epoch, so nothing has to be cleared between launches.
 // Same arithmetic and same slot order as the three kernels it replaces: images are bit-identical (tests).
+// Slots per thread: 2 (round 4; 4 until then).  With four the kernel needs 128 registers and spills 18 of them at four
+// wavefronts per SIMD; with two it needs 88, spills nothing and runs five: config 2 +1.7 %, config 3 +-0 ... +1 %
+// (profiles/r04_config2_counters.txt).  Six wavefronts (80 registers) spill 53.
 #ifndef PT_FUSE_K
-#define PT_FUSE_K 4
+#define PT_FUSE_K 2
 #endif
 
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
 constexpr int kFuseK = PT_FUSE_K;
 constexpr uint32_t kFuseTile = 256u * kFuseK;
-static_assert(kFuseTile == 256u * kListPer, "k_raygen / k_spheres scan their work lists on k_shade_fused's tile descriptors");
+static_assert(kFuseTile <= 256u * kListPer, "k_raygen / k_spheres scan their work lists on k_shade_fused's tile descriptors");
 
 
 // exclusive prefix of `tile` (survivors of tiles [0, tile)), by the calling wavefront; every lane returns it
@@ -2630,7 +2636,7 @@ __device__ __forceinline__ uint32_t tile_lookback(const unsigned long long* desc
 template <bool kSpheres, bool kFirst>
 // (occupancy bounds re-measured on the final build: at least 5 or 6 wavefronts per SIMD forces spills, -8 % / -13 % end
 // to end; 1 to 3 compile to the same 124 registers)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, 8))) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
                                                      int staged, int bounce, int last_bounce, const uint32_t* slot_base,
                                                      unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb,
                                                      DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi, const uint32_t* list)
@@ -2705,12 +2711,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       if (!kFirst) tp[j] = ldnt(&hits.tp[s]);
     }
   }
-  // the sphere run that ends the object list: every lane with its own candidates, all four slots at once, when the run
+  // the sphere run that ends the object list: every lane with its own candidates, all its slots at once, when the run
   // allows it (sphere_run_lanes); object by object otherwise
   const bool lanes_run = kSpheres && PT_SPHERE_LANES && sc.lanes_run != 0u;
   if (kSpheres && lanes_run) {
-    static_assert(kFuseK == 4, "sphere_run_lanes: four slots");
-    const uint32_t valid = (slot_of[0] < n_all ? 1u : 0u) | (slot_of[1] < n_all ? 2u : 0u) | (slot_of[2] < n_all ? 4u : 0u) | (slot_of[3] < n_all ? 8u : 0u);
+    static_assert(kFuseK <= 4, "sphere_run_lanes: at most four slots");
+    uint32_t valid = 0u;
+#pragma unroll
+    for (int j = 0; j < kFuseK; ++j) valid |= slot_of[j] < n_all ? 1u << j : 0u;
     have_nm |= sphere_run_lanes<kFuseK>(sc, obj_begin, obj_end, o4, d4, tp, nm, valid);
   }
 #pragma unroll

@@ -11,6 +11,6 @@ grep -h '^{"metric"' $OUT/bench_steps20.log $OUT/bench_default.log $OUT/bench_st
 import sys, json
 for l in sys.stdin:
     j = json.loads(l); r = j['roofline']
-    print(j['value'], j['ms_per_step'], 'frac', r['frac'], 'launch', r['avg_launch_us'], 'traffic', r['traffic'], 'valu', (r.get('valu') or {}).get('valu_pipe_frac'), 'parity', j['parity']['bit_exact'], 'steady', (j.get('steady_state') or {}).get('value'))
+    print(j['value'], j['ms_per_step'], 'frac', r['frac'], 'launch', r['avg_launch_us'], 'traffic', r['traffic'], 'valu', (r.get('valu') or {}).get('valu_pipe_frac'), 'parity', (j.get('parity') or {}).get('bit_exact'), 'steady', (j.get('steady_state') or {}).get('value'))
 "
 tail -3 $OUT/kernel_stats_steps20.txt
