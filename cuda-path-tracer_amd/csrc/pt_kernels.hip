@@ -2584,8 +2584,8 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 //   * descriptors carry the launch's epoch, so nothing has to be cleared between launches.
 // Same arithmetic and same slot order as the three kernels it replaces: images are bit-identical (tests).
 // Slots per thread: 2 (round 4; 4 until then).  With four the kernel needs 128 registers and spills 18 of them at four
-// wavefronts per SIMD; with two it needs 88, spills nothing and runs five: config 2 +1.7 %, config 3 +-0 ... +1 %
-// (profiles/r04_config2_counters.txt).  Six wavefronts (80 registers) spill 53.
+// wavefronts per SIMD; with two it needs 88, spills nothing and runs five: config 2 +2.2 %, config 3 +0.6 ... 1.2 %;
+// one slot (eight wavefronts): -4 ... -6 % (profiles/r04_config2_counters.txt).  Six wavefronts (80 registers) spill 53.
 #ifndef PT_FUSE_K
 #define PT_FUSE_K 2
 #endif
