@@ -2333,7 +2333,12 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 // irrelevant -- results are written per slot), and the traversal launch fetches its rays through that list.  In the
 // Cornell-box scenes most rays of most bounces never come near the meshes.
 template <bool kFirst, bool kFilter>
-__global__ __launch_bounds__(256) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
+// (at least six wavefronts per SIMD: 80 registers, 3-14 spilled, against 92 and five wavefronts: config 2 +2.7 %; seven: +1.7 %,
+// eight (49-62 spilled): +1.1 %; profiles/r04_config2_counters.txt)
+#ifndef PT_SPHERES_WAVES
+#define PT_SPHERES_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SPHERES_WAVES, 8))) void k_spheres(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths paths, DHits hits,
                                                  int bounce, DeviceCounters* counters, DBatchInfo bi, uint32_t filt_begin,
                                                  uint32_t filt_end, uint32_t* worklist, DTileScan scan, uint32_t tile_stride)
 {

@@ -187,8 +187,8 @@ struct ptc_ctx {
   uint64_t scene_serial = 0;  // counts ptc_upload_scene calls (entry points computed for another scene are stale)
   uint32_t beam_tiles_x = 0, beam_tiles_y = 0;
   uint32_t traverse_waves = 5120;
-  uint32_t refill_lanes = 20;
-  uint32_t static_eighths = 3;
+  uint32_t refill_lanes = 32;   // (20 until round 4: re-swept on its final code, profiles/r04_schedules.txt)
+  uint32_t static_eighths = 4;  // (3 until round 4)
   bool merge_instances = true;  // "merge_instances": consecutive instances of one mesh walked by one launch (k_traverse4m)
   bool bvh_on_device = true;  // "bvh_build_on_device": the reference BVH of ptc_upload_scene from pt_bvh_gpu.hip
   bool layout_on_device = true;  // "layout_on_device": the traversal layouts derived from it, too

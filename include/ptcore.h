@@ -286,8 +286,8 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "split_idle"       once a traversal launch has handed out its last ray: idle lanes of a persistent wavefront that
  *                      trigger work splitting (an idle lane takes over the bottom of a busy lane's traversal stack
  *                      with a copy of its ray; default 8, 0 = never).  Cuts the latency tail of every launch
- *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 20)
- *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 3 = 3/8)
+ *   "refill_lanes"     idle lanes of a persistent wavefront that trigger the next ray fetch (default 32; 20 until round 4)
+ *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 4 = 4/8; 3 until round 4)
  *   "small_waves", "small_rays_per_lane"  a traversal launch with fewer than small_rays_per_lane (default 4) rays per lane of
  *                      "traverse_waves" wavefronts uses at most small_waves (default 3072) of them
  *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small

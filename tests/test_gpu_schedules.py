@@ -312,8 +312,8 @@ def test_benchmark_size_soak_across_schedules(pkg, big):
     spill to global memory -- accumulate the same image bit for bit: a single differing hit anywhere would change
     every later random number of its frame."""
     scene, flat, depth = big
-    runs = [(), (("frames_in_flight", 8), ("batch_frames", 1), ("traverse_waves", 1024)),
-            (("frames_in_flight", 32), ("batch_frames", 8), ("traverse_waves", 2048), ("static_eighths", 7))]
+    runs = [(), (("frames_in_flight", 8), ("batch_frames", 1), ("traverse_waves", 1024), ("refill_lanes", 20), ("static_eighths", 3)),
+            (("frames_in_flight", 32), ("batch_frames", 8), ("traverse_waves", 2048), ("static_eighths", 7), ("refill_lanes", 48))]
     ref = frames(pkg, scene, flat, 1920, 1080, 160, 8, params=runs[0])
     for params in runs[1:]:
         assert same(frames(pkg, scene, flat, 1920, 1080, 160, 8, params=params), ref), params
