@@ -404,6 +404,14 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             handle, err = (pt.band_export() if rank else b""), None
         except Exception as exc:   # noqa: BLE001 -- reported, not fatal: the RCCL figure stands
             handle, err = None, repr(exc)
+        # (the pull kernel reads the peers' buffers in place: where the root's GPU cannot address a peer's memory the leg is
+        # skipped and says so, rather than finding out inside a kernel)
+        if rank and not rehearse and err is None:
+            try:
+                if not torch.cuda.can_device_access_peer(0, local_rank):
+                    err = f"cuda:0 cannot access cuda:{local_rank} (no peer access)"
+            except Exception as exc:   # noqa: BLE001
+                err = "peer-access query failed: " + repr(exc)
         handles = [None] * world
         dist.all_gather_object(handles, (handle, err))
         state = [None]
@@ -423,11 +431,16 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                     pt.band_publish("color")
                 dist.barrier()
                 if rank == 0:
-                    pt.gather_frame("color", frame.data_ptr())
-                    us.append(pt.gather_last_us())
+                    try:
+                        pt.gather_frame("color", frame.data_ptr())
+                        us.append(pt.gather_last_us())
+                    except Exception as exc:   # noqa: BLE001 -- reported in the line, the RCCL figure stands
+                        state[0] = repr(exc)
                 dist.barrier()
-            gather["ipc_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
-            gather["transports_agree"] = bool(torch.equal(rccl_frame, frame)) if rank == 0 else None   # the same assembled frame, bit for bit
+            gather["ipc_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 and us else None
+            gather["transports_agree"] = bool(torch.equal(rccl_frame, frame)) if rank == 0 and state[0] is None else None   # the same assembled frame, bit for bit
+            if rank == 0 and state[0] is not None:
+                gather["ipc_error"] = state[0]
             gather["ipc_note"] = ("ptc_gather_frame: one kernel on the root reads every rank's band where it lies (HIP IPC "
                                   "mapping; xGMI between GPUs) and writes row order; device time, median of 5")
         else:
