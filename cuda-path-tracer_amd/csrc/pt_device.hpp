@@ -161,7 +161,8 @@ struct DScene {
   // per object kSphereTab float4, for spheres: [0] the world-space ball that contains the transformed sphere {centre.xyz,
   // radius (rounded up)} -- radius < 0: no ball (a projective matrix; a mesh object): never skipped; [1] {1 / largest
   // stretch of the object's matrix (rounded down), 1 if "simple" (both matrices pure translations spelled 1.0f / +0.0f),
-  // 0, 0}; [2..6] what a lane needs of a simple object: {box min, inverse translation x}, {box max, .. y},
+  // radius of the INNER ball of a simple object (inside what the reference's float sequence can hit; sphere_ball_of), 0};
+  // [2..6] what a lane needs of a simple object: {box min, inverse translation x}, {box max, .. y},
   // {sphere centre, .. z}, {translation, sphere radius}, {material bits, 0, 0, 0} (sphere_run_lanes).
   const float4* sphere_ball;
   uint32_t lanes_run;              // set per launch by the host: the launch's sphere run may take sphere_run_lanes

@@ -22,6 +22,9 @@
 #include "pt_rng.hpp"
 #include "pt_beam_rules.hpp"
 #include "pt_feed_rules.hpp"
+static_assert(pt::beam_rules::kLeaf == pt::kLeafBit, "pt_beam_rules.hpp restates the leaf bit of the four-wide node (pt_device.hpp)");
+static_assert((uint32_t)pt::beam_rules::kEntries == pt::kBeamEntries, "pt_beam_rules.hpp restates the entries per tile (pt_device.hpp)");
+static_assert(pt::feed_rules::kBatch == (uint32_t)pt::kWave, "a feed batch is one wavefront's worth of rays");
 
 #include <float.h>
 
@@ -1332,12 +1335,15 @@ __device__ __forceinline__ uint32_t sphere_candidates(const DScene& sc, const ui
       const float r2 = R * R;
       const float dd = __builtin_fmaf(bh, bh, -(oc2 - r2));
       const float m = 1e-5f * (__builtin_fmaf(bh, bh, oc2) + r2);
-      const float sq_up = __builtin_amdgcn_sqrtf(fmaxf(dd + m, 0.0f)), sq_dn = __builtin_amdgcn_sqrtf(fmaxf(dd - m, 0.0f));
+      // the inner ball (sphere_ball_of): what is hit for sure, and the bounds from the other side
+      const float Rin = sc.sphere_ball[(size_t)kSphereTab * i + 1u].z;
+      const float dd_in = __builtin_fmaf(bh, bh, -(oc2 - Rin * Rin));
+      const float sq_up = __builtin_amdgcn_sqrtf(fmaxf(dd + m, 0.0f)), sq_dn = __builtin_amdgcn_sqrtf(fmaxf(dd_in - m, 0.0f));
       const float e = 1e-5f * (fabsf(bh) + sq_up + R) + 1e-6f;
       const bool near_bad = -bh - sq_dn < tmin - e;   // the nearer root is surely below t_min: only the farther one counts
       const bool near_ok = -bh - sq_up > tmin + e;    // ... surely at or above it: it is the one
       const bool missed = dd < -m || -bh + sq_up < tmin - e;
-      const bool sure = dd > m && (near_ok || (near_bad && -bh + sq_dn > tmin + e));
+      const bool sure = dd_in > m && (near_ok || (near_bad && -bh + sq_dn > tmin + e));
       const float lo = near_bad ? -bh + sq_dn - e : -bh - sq_up - e;
       const float hi = near_ok ? -bh - sq_dn + e : -bh + sq_up + e;
       const bool known = m < __builtin_inff();        // (anything non-finite: a candidate, and no bound from it)

@@ -299,10 +299,9 @@ static void sphere_ball_of(const ptc_object& o, const ptc_sphere* spheres, uint3
   // smaller of it and the Frobenius norm, but never less than the iterate
   double gersh = 0.0;
   for (int i = 0; i < 3; ++i) gersh = std::max(gersh, std::fabs(g[i][0]) + std::fabs(g[i][1]) + std::fabs(g[i][2]));
+  // (only proven bounds: the iterate approaches from below and is no bound, however close -- round 4 took "iterate plus
+  // 1 %" when that was smaller, which an anisotropic matrix with a slowly converging iteration could undercut)
   double lam_up = std::min(gersh, frob2);
-  // (for a rotation times a uniform scale G is s^2 I: Gershgorin is exact.  Otherwise the iterate plus 1 % is used when it
-  // is below the proven bound -- and the skip test's own margins are relative 1e-4, so the 1 % only costs pruning)
-  lam_up = std::min(lam_up, lam * 1.02);
   lam_up = std::max(lam_up, lam);
   const double sigma = std::sqrt(lam_up) * (1.0 + 1e-6);
   const double cx = a[0][0] * sp.center[0] + a[0][1] * sp.center[1] + a[0][2] * sp.center[2] + (double)m[12];
@@ -311,9 +310,21 @@ static void sphere_ball_of(const ptc_object& o, const ptc_sphere* spheres, uint3
   const double rad = std::fabs((double)sp.radius) * sigma;
   if (!std::isfinite(cx + cy + cz + rad)) return;
   const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
+  // What separates the ball the kernels compute with from the sphere the reference's float sequence sees, as a length:
+  // the rounding of the centre to float (slack); the one rounding of `origin + inverse translation` in inverse_transform_ray,
+  // which is relative to the OBJECT-space origin and so carries 2^-24 of the sphere's own centre; and the rounding of the hit
+  // point back in world space (2^-24 of its coordinates), which moves the distance the reference records against the root.
+  // The OUTER ball (radius + that) contains what the reference can hit: it decides "missed" and the lower bounds; the INNER
+  // ball (radius - that, row 1 .z) lies inside it: "surely hit" and the upper bounds come from it (round 4 took the outer
+  // radius for both, which is the wrong way round for the latter -- a small sphere far from the origin).
   const double slack = std::fabs(cx - fx) + std::fabs(cy - fy) + std::fabs(cz - fz);
-  float fr = (float)((rad + slack) * (1.0 + 1e-6));
+  const double coord = std::fabs(cx) + std::fabs(cy) + std::fabs(cz) + std::fabs((double)sp.center[0]) + std::fabs((double)sp.center[1]) +
+                       std::fabs((double)sp.center[2]) + 3.0 * rad;
+  const double cerr = slack + coord * (1.0 / 4194304.0);  // 2^-22
+  float fr = (float)((rad + cerr) * (1.0 + 1e-6));
   fr = std::nextafter(fr, INFINITY);
+  float fin = (float)(std::max(0.0, std::fabs((double)sp.radius) * (1.0 - 1e-6) - cerr) * (1.0 - 1e-6));
+  fin = fin > 0.0f ? std::nextafter(fin, 0.0f) : 0.0f;
   float inv_sigma = (float)((1.0 / sigma) * (1.0 - 1e-6));
   inv_sigma = std::nextafter(inv_sigma, 0.0f);
   out[0] = make_float4(fx, fy, fz, fr);
@@ -332,7 +343,7 @@ static void sphere_ball_of(const ptc_object& o, const ptc_sphere* spheres, uint3
       }
     }
   for (int r = 0; r < 3; ++r) simple = simple && std::isfinite(o.m[12 + r]) && std::isfinite(o.inv_m[12 + r]);
-  out[1] = make_float4(inv_sigma, simple ? 1.0f : 0.0f, 0.f, 0.f);
+  out[1] = make_float4(inv_sigma, simple ? 1.0f : 0.0f, simple ? fin : 0.0f, 0.f);  // (.z: a simple object does not stretch)
   float mat_f;
   std::memcpy(&mat_f, &material, 4);
   out[2] = make_float4(o.aabb_min[0], o.aabb_min[1], o.aabb_min[2], o.inv_m[12]);

@@ -317,39 +317,76 @@ SceneDescription scene_from_json(const std::string& filename)
   return scene;
 }
 
-// ---------------------------------------------------------------- OBJ (first object's triangles, fan triangulation)
+// ---------------------------------------------------------------- OBJ (the file's first mesh, fan triangulation)
+// The reference keeps assimp's mMeshes[0] only (model_loader.cpp:22).  assimp's OBJ importer opens a new mesh at every
+// `o` / `g` statement that names another object or group and at every `usemtl` that names another material, and drops
+// meshes without faces: mMeshes[0] is the first such chunk that holds a face.  Kept here: the faces of that chunk, and of
+// the file's vertices the ones those faces use (assimp's mesh carries its own vertices, and GenBoundingBoxes bounds those),
+// in file order.  (assimp does not join identical vertices under the reference's flags, so ITS vertex array has three
+// entries per triangle; the positions a triangle's indices lead to are the same, and nothing on the path depends on more.)
 Mesh load_obj(const std::string& filename)
 {
   std::ifstream file(filename);
   if (!file.is_open()) throw std::runtime_error("Unable to load " + filename);
   Mesh mesh;
-  std::string line;
+  std::vector<float> all;          // every `v` of the file
+  std::vector<uint32_t> faces;     // the first mesh's triangles, indices into `all`
+  std::string line, cur_o, cur_g, cur_m;
+  bool closed = false;             // the first mesh is complete: a later chunk has begun
+  auto name_of = [](const std::string& l, size_t from) {
+    size_t a = l.find_first_not_of(" \t\r", from), b = l.find_last_not_of(" \t\r");
+    return a == std::string::npos ? std::string() : l.substr(a, b - a + 1);
+  };
   while (std::getline(file, line)) {
     if (line.size() < 2) continue;
     if (line[0] == 'v' && line[1] == ' ') {
       float x, y, z;
       if (std::sscanf(line.c_str() + 2, "%f %f %f", &x, &y, &z) == 3) {
-        mesh.positions.push_back(x);
-        mesh.positions.push_back(y);
-        mesh.positions.push_back(z);
+        all.push_back(x);
+        all.push_back(y);
+        all.push_back(z);
       }
-    } else if (line[0] == 'f' && line[1] == ' ') {
+    } else if ((line[0] == 'o' || line[0] == 'g') && (line[1] == ' ' || line[1] == '\t')) {
+      std::string& cur = line[0] == 'o' ? cur_o : cur_g;
+      const std::string name = name_of(line, 1);
+      if (name != cur && !faces.empty()) closed = true;
+      cur = name;
+    } else if (line.compare(0, 7, "usemtl ") == 0) {
+      const std::string name = name_of(line, 6);
+      if (name != cur_m && !faces.empty()) closed = true;
+      cur_m = name;
+    } else if (line[0] == 'f' && line[1] == ' ' && !closed) {
       std::vector<uint32_t> face;
       std::istringstream ss(line.substr(2));
       std::string tok;
       while (ss >> tok) {
         const long idx = std::strtol(tok.c_str(), nullptr, 10);  // "a", "a/b", "a/b/c", "a//c"
-        const long count = (long)(mesh.positions.size() / 3);
+        const long count = (long)(all.size() / 3);
         face.push_back((uint32_t)(idx < 0 ? count + idx : idx - 1));
       }
       for (size_t k = 1; k + 1 < face.size(); ++k) {
-        mesh.indices.push_back(face[0]);
-        mesh.indices.push_back(face[k]);
-        mesh.indices.push_back(face[k + 1]);
+        faces.push_back(face[0]);
+        faces.push_back(face[k]);
+        faces.push_back(face[k + 1]);
       }
     }
   }
-  if (mesh.positions.empty() || mesh.indices.empty()) throw std::runtime_error("Unable to load " + filename);
+  if (all.empty() || faces.empty()) throw std::runtime_error("Unable to load " + filename);
+  // the vertices the mesh uses, in file order
+  const size_t nv = all.size() / 3;
+  std::vector<uint32_t> remap(nv, 0xffffffffu);
+  for (uint32_t v : faces) {
+    if (v >= nv) throw std::runtime_error("Unable to load " + filename + ": face index out of range");
+    remap[v] = 0u;
+  }
+  uint32_t next = 0;
+  for (size_t v = 0; v < nv; ++v)
+    if (remap[v] == 0u) {
+      remap[v] = next++;
+      mesh.positions.insert(mesh.positions.end(), all.begin() + 3 * (long)v, all.begin() + 3 * (long)v + 3);
+    }
+  mesh.indices.reserve(faces.size());
+  for (uint32_t v : faces) mesh.indices.push_back(remap[v]);
   for (int a = 0; a < 3; ++a) mesh.aabb_min[a] = mesh.aabb_max[a] = mesh.positions[(size_t)a];
   for (size_t v = 0; v < mesh.positions.size() / 3; ++v)
     for (int a = 0; a < 3; ++a) {

@@ -13,21 +13,41 @@ from .scene_description import (Camera, DielectricMaterial, DiffuseMateral, Mesh
 
 
 def load_obj(filename):
-    positions, indices = [], []
+    """model_loader.cpp:11-44 keeps assimp's mMeshes[0] only.  assimp's OBJ importer opens a new mesh at every `o` / `g` that
+    names another object or group and at every `usemtl` that names another material, and drops meshes without faces: the
+    first chunk that holds a face is kept, with the vertices its faces use (file order); fan triangulation.  The same rule
+    as host/scene_description.cpp (tests/test_cli_frontend.py compares the two)."""
+    positions, faces = [], []
+    cur = {"o": "", "g": "", "usemtl": ""}
+    closed = False
     with open(filename) as f:
         for line in f:
             if line.startswith("v "):
                 positions.append([float(x) for x in line.split()[1:4]])
-            elif line.startswith("f "):
+                continue
+            key = line.split(None, 1)[0] if line.strip() else ""
+            if key in cur and line[len(key):len(key) + 1] in (" ", "\t"):
+                name = line[len(key):].strip()
+                if name != cur[key] and faces:
+                    closed = True
+                cur[key] = name
+            elif line.startswith("f ") and not closed:
                 face = []
                 for tok in line.split()[1:]:
                     idx = int(tok.split("/")[0])
                     face.append(len(positions) + idx if idx < 0 else idx - 1)
                 for k in range(1, len(face) - 1):
-                    indices += [face[0], face[k], face[k + 1]]
-    if not positions or not indices:
+                    faces += [face[0], face[k], face[k + 1]]
+    if not positions or not faces:
         raise ValueError(f"Unable to load {filename}")
-    return Mesh(np.array(positions, dtype=np.float32), np.array(indices, dtype=np.uint32))
+    positions = np.array(positions, dtype=np.float32)
+    faces = np.array(faces, dtype=np.int64)
+    if faces.min() < 0 or faces.max() >= len(positions):
+        raise ValueError(f"Unable to load {filename}: face index out of range")
+    used = np.zeros(len(positions), dtype=bool)
+    used[faces] = True
+    remap = np.cumsum(used) - 1
+    return Mesh(positions[used], remap[faces].astype(np.uint32))
 
 
 def _command(j):

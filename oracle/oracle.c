@@ -321,6 +321,12 @@ float orc_aabb_surface_area(const OAABB* b)
   const ovec3 d = vsub(b->max, b->min);
   return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
 }
+/* aabb.hpp:41-44: extent() = max - min */
+void orc_aabb_extent(const OAABB* b, float* out)
+{
+  const ovec3 e = vsub(b->max, b->min);
+  out[0] = e.x; out[1] = e.y; out[2] = e.z;
+}
 int orc_aabb_max_extent(const OAABB* b)
 {
   const ovec3 e = vsub(b->max, b->min);

@@ -120,6 +120,7 @@ void orc_make_object(uint32_t type, uint32_t index, const omat4* m, const OSpher
                      const OAABB* mesh_aabb, OObject* out);
 
 float    orc_aabb_surface_area(const OAABB* b);                 /* aabb.hpp:62-68 */
+void     orc_aabb_extent(const OAABB* b, float* out3);          /* aabb.hpp:41-44 */
 int      orc_aabb_max_extent(const OAABB* b);                   /* aabb.hpp:51-55 */
 void     orc_aabb_offset(const OAABB* b, const float* p, float* out); /* aabb.hpp:73-80 */
 

@@ -91,6 +91,8 @@ def lib():
         h.orc_make_object.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         h.orc_aabb_surface_area.restype = C.c_float
         h.orc_aabb_surface_area.argtypes = [C.c_void_p]
+        h.orc_aabb_extent.restype = None
+        h.orc_aabb_extent.argtypes = [C.c_void_p, C.c_void_p]
         h.orc_aabb_max_extent.restype = C.c_int
         h.orc_aabb_max_extent.argtypes = [C.c_void_p]
         h.orc_aabb_offset.restype = None

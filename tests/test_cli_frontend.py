@@ -63,6 +63,48 @@ def test_cpp_front_end_flattens_like_python(pkg, tmp_path, scene_file):
     assert tuple(cpp["tail"][:2]) == tuple(py.resolution) and cpp["tail"][2] == py.spp
 
 
+def test_obj_keeps_the_first_mesh_only(pkg, tmp_path):
+    """model_loader.cpp:22 takes assimp's mMeshes[0]: of a file with several objects / groups / materials only the first chunk
+    that holds faces, with the vertices those faces use.  Both readers, on a file whose first `o` is empty, whose second
+    holds a quad and a triangle (negative and a/b/c indices), and whose later chunks (another `o`, another `usemtl`) must
+    not be read; an unused vertex in front must not end up in the mesh (assimp's mesh has its own vertices, and its box
+    bounds those)."""
+    _ensure_cli()
+    root = tmp_path / "assets"
+    (root / "models").mkdir(parents=True)
+    (root / "scenes").mkdir()
+    (root / "models" / "two.obj").write_text(
+        "# two objects\n"
+        "o empty\n"
+        "v 9 9 9\n"                      # used by nobody in the first mesh
+        "o first\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 0.5 1\n"
+        "usemtl a\n"
+        "f 2/1/1 3/2/1 4/3/1 5/4/1\n"      # a quad: two triangles
+        "f -1 -5 -4\n"                    # relative indices: vertex 6, 2, 3
+        "usemtl a\n"                      # the same material again: no new mesh
+        "f 2 4 6\n"
+        "usemtl b\n"                      # another material: assimp's second mesh
+        "f 1 2 3\n"
+        "o second\n"
+        "v 5 5 5\nv 6 5 5\nv 5 6 5\n"
+        "f 7 8 9\n")
+    (root / "scenes" / "two.json").write_text(
+        '{"camera": {"vfov": 45, "transform": {"from": [0, 0, 4], "at": [0, 0, 0], "up": [0, 1, 0]}, "resolution": [32, 32]},'
+        ' "materials": [{"name": "m", "type": "lambertian", "albedo": [0.5, 0.5, 0.5]}],'
+        ' "surfaces": [{"type": "mesh", "filename": "../models/two.obj", "material": "m", "transform": {"translate": [0, 0, 0]}}]}')
+    mesh = pkg.json_parser.load_obj(str(root / "models" / "two.obj"))
+    assert mesh.positions.shape == (5, 3) and np.array_equal(mesh.positions[0], [0, 0, 0]) and np.array_equal(mesh.positions[4], [0.5, 0.5, 1])
+    assert [int(i) for i in mesh.indices] == [0, 1, 2, 0, 2, 3, 4, 0, 1, 0, 2, 4]
+    dump = tmp_path / "scene.bin"
+    subprocess.run([HIP_PT, "--dump-scene", str(dump), "scenes/two.json"], cwd=str(root / "scenes"), check=True)
+    cpp = _parse_dump(str(dump), pkg)
+    assert np.array_equal(cpp["positions"], mesh.positions.reshape(-1))
+    assert np.array_equal(cpp["indices"], mesh.indices)
+    flat = pkg.json_parser.scene_from_json(str(root / "scenes" / "two.json")).build_scene()
+    assert np.allclose(cpp["objects"]["aabb_min"], flat.objects["aabb_min"]) and np.allclose(flat.objects["aabb_max"][0], [1, 1, 1])
+
+
 def test_cli_errors_and_flags(tmp_path):
     _ensure_cli()
     r = subprocess.run([HIP_PT], capture_output=True, text=True)

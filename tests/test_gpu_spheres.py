@@ -213,3 +213,42 @@ def test_scaled_instances_behind_closer_spheres(pkg, orc):
         assert np.array_equal(plain[k], ref[k]), (k, "filter_rays 0", int(np.sum(plain[k] != ref[k])))
         assert np.array_equal(got[k], ref[k]), (k, int(np.sum(got[k] != ref[k])))
     assert got["rays"] == ref["rays"]
+
+
+@pytest.mark.parametrize("shift", [(1000.0, 800.0, -1200.0), (9000.0, -7000.0, 4000.0), (0.0, 0.0, 0.0)])
+@pytest.mark.parametrize("with_mesh", [False, True])
+def test_small_spheres_far_from_the_origin(pkg, orc, shift, with_mesh):
+    """Round 4's advisor finding: the candidate bounds of sphere_candidates took the INFLATED ball (radius + the float
+    rounding of its centre) also for "surely hit" and for the upper bounds, which is the wrong way round -- a ray that
+    grazes just outside a small sphere far from the origin was declared a sure hit, capped the list, and the wall behind it
+    was dropped.  Every other case in this file has a zero centre or a zero translation (no rounding of the centre at all).
+    Here: spheres with their centre in the Sphere struct AND a translation of 1e3 .. 1e4 (the world centre is not a float),
+    a wall behind them, the camera about a unit away so that a good share of the rays graze; without a mesh the run ends the
+    object list (k_shade_fused, caps of the earlier objects only), with a mesh at the end it stands in front of one
+    (k_spheres); per-lane candidates on and off."""
+    glm = pkg.glmlite
+    s = pkg.SceneDescription()
+    s.resolution = (160, 96)
+    sx, sy, sz = shift
+    s.camera = pkg.Camera(position=(sx + 0.3, sy + 0.25, sz + 1.6), rotation=(1.0, 0.0, 0.0, 0.0), vfov=float(np.radians(55)))
+    s.add_material("white", pkg.DiffuseMateral((0.8, 0.8, 0.8)))
+    s.add_material("red", pkg.DiffuseMateral((0.8, 0.2, 0.2)))
+    s.add_material("mirror", pkg.MetalMaterial((0.9, 0.9, 0.9), 0.0))
+    s.add_material("glass", pkg.DielectricMaterial(1.5))
+    s.add_object(pkg.Sphere((0.3, 0.2, 0.1), 0.5), glm.translate(shift), "red")
+    s.add_object(pkg.Sphere((-0.55, 0.25, 0.2), 0.35), glm.translate(shift), "glass")          # touches the first one's silhouette
+    s.add_object(pkg.Sphere((0.31, 0.2, 0.1), 0.5), glm.translate(shift), "mirror")            # nearly coincident with the first
+    s.add_object(pkg.Sphere((0.0, 0.0, -1003.0), 1000.0), glm.translate(shift), "white")       # the wall behind them
+    s.add_object(pkg.Sphere((0.0, -1000.4, 0.0), 1000.0), glm.translate(shift), "white")       # a floor
+    if with_mesh:
+        mesh = pkg.scenes.heightfield_mesh(17, 9, 1.0, 0.5, seed=3)
+        s.add_mesh("ground", mesh)
+        s.add_object(mesh, glm.translate((sx, sy - 0.3, sz + 0.4)), "white")
+    flat = s.build_scene()
+    w, h, iters, mb = 160, 96, 2, 6
+    ref = orc.render_streaming(flat, s.camera, w, h, 0, iters, mb)
+    for params in ((), (("sphere_lanes", 0), ("sphere_fold", 0)), (("fused_shade", 0),)):
+        got = _frames(pkg, s, flat, w, h, iters, mb, params=params)
+        for k in ("color", "normal", "depth"):
+            assert np.array_equal(got[k], ref[k]), (shift, with_mesh, params, k, int(np.sum(got[k] != ref[k])))
+        assert got["rays"] == ref["rays"]
