@@ -154,7 +154,7 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
                     % (traffic_rec.get("frames_per_launch"), (traffic_rec.get("trace_kernel_hbm_bytes_per_launch") or 0) / 1e9,
                        frames_per_launch))
     roof = {
-        "bound": "hbm",
+        "bound": "hbm", "priced_against": "hbm",
         "kernel": "k_traverse4 (closest hit: persistent wavefronts over the 4-wide quantised BVH, %d frames per launch)" % frames_per_launch,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": traffic, "traffic_note": note,
@@ -200,19 +200,50 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
         roof["valu"] = {k: sq.get(k) for k in ("valu_pipe_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
                                                 "salu_inst_per_ray", "l2_hit_frac", "wave_occupancy_frac", "frames_per_launch",
                                                 "matches_this_run", "source")}
+        raw = sq.get("raw_means_per_launch") or {}
+        us, clk = sq.get("mean_launch_us_serialised_by_the_profiler"), sq.get("shader_clock_ghz")
+        if raw.get("TCP_TOTAL_CACHE_ACCESSES_sum") and us and clk:
+            # vector-L1 tag look-ups per shader cycle and CU (256 CUs): a 64-byte node record is four of them
+            roof["valu"]["l1_tag_accesses_per_cycle_per_cu"] = round(raw["TCP_TOTAL_CACHE_ACCESSES_sum"] / (us * 1e-6 * clk * 1e9 * 256), 3)
+        # what the counters say binds the kernel: VALU issue at under half the lanes, and the vector L1's
+        # tag rate; the fabric carries a quarter of its peak.  The SURVEY 8(d) HBM pricing stays in achieved / peak / frac.
+        roof["bound"] = "valu-issue / vL1D"
+        roof["bound_note"] = ("from counters (profiles/pmc_sq_*.json): VALU pipe %.2f at %.1f of 64 lanes, %s L1 tag accesses per cycle and CU, "
+                              "L2 hit rate %.2f; fabric traffic is a quarter of the HBM peak -- achieved / peak / frac price the kernel "
+                              "against HBM as SURVEY 8(d) prescribes (priced_against), they do not name what binds it"
+                              % (sq.get("valu_pipe_frac") or 0, sq.get("lanes_per_valu_inst") or 0,
+                                 roof["valu"].get("l1_tag_accesses_per_cycle_per_cu"), sq.get("l2_hit_frac") or 0))
     return roof
 
 
-def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
-    coll_dev = "cpu" if rehearse else "cuda"
+def _gather_floats(dist, group, world, value):
+    """every rank's value (control plane: objects over the gloo group, outside any timed region)"""
+    out = [None] * world
+    dist.all_gather_object(out, float(value), group=group)
+    return out
+
+
+_SCENES = {}
+
+
+def config3_scene(pkg, W, H, grid):
+    """The benchmark scene, its flattened arrays and the host-built reference BVH (the tree the CPU oracle walks), built once
+    per process: the extra legs of a run (rank_share, reference_order_gpu, config 5) reuse them."""
+    key = (W, H, grid)
+    if key not in _SCENES:
+        nx, nz = (int(v) for v in grid.split("x"))
+        scene = pkg.scenes.heightfield_scene((W, H), nx=nx, nz=nz)
+        flat = scene.build_scene()
+        mesh = list(scene.mesh_map_.values())[0]
+        t0 = time.perf_counter()
+        flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)       # host builder: the tree the CPU oracle walks (parity, cpu_baseline)
+        _SCENES[key] = (scene, flat, bvh_depth, time.perf_counter() - t0)
+    return _SCENES[key]
+
+
+def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse, ctl=None):
     W, H, MB = args.width or 1920, args.height or 1080, args.max_bounces
-    nx, nz = (int(v) for v in args.grid.split("x"))
-    scene = pkg.scenes.heightfield_scene((W, H), nx=nx, nz=nz)
-    flat = scene.build_scene()
-    mesh = list(scene.mesh_map_.values())[0]
-    t0 = time.perf_counter()
-    flat.bvh, bvh_depth = pkg.bvh_from_mesh(mesh)       # host builder: the tree the CPU oracle walks (parity, cpu_baseline)
-    bvh_build_s = time.perf_counter() - t0
+    scene, flat, bvh_depth, bvh_build_s = config3_scene(pkg, W, H, args.grid)
     import copy
     bare = copy.copy(flat)
     bare.bvh = None   # the tracer gets the scene as the reference's front end hands it over: the library builds BVH and layouts (on the GPU)
@@ -267,21 +298,38 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
 
     # N > 1: who is really there.  rccl_ranks = what a device all-reduce of ones over the process group sums to, counted only
     # when the group's backend for CUDA tensors is nccl (= RCCL); distinct_devices = distinct PCI identities of the ranks' GPUs.
-    rccl_ranks = distinct_devices = None
+    rccl_ranks = distinct_devices = rccl_error = None
+    data_ok = [True]            # the default process group (RCCL; gloo in a rehearsal) carries collectives
+    gather_fallback = [None]
     if world > 1:
         props = torch.cuda.get_device_properties(local_rank)
         ident = tuple(str(getattr(props, k)) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(props, k)) or None
         idents = [None] * world
-        dist.all_gather_object(idents, ident)
+        dist.all_gather_object(idents, ident, group=ctl)
         distinct_devices = len(set(idents)) if all(i is not None for i in idents) else None
         if rehearse:
             rccl_ranks = 0
         else:
-            ones = torch.ones(1, dtype=torch.int32, device="cuda")
-            dist.all_reduce(ones)
-            torch.cuda.synchronize()
-            rccl_ranks = int(ones.item()) if "nccl" in str(dist.get_backend()) else 0
-            if rccl_ranks != world:
+            # the first collective over RCCL.  If it throws (no peer access, an IPC failure at communicator set-up) the run goes
+            # on: frames are traced without any collective, control messages travel over the gloo group, the present-time gather
+            # falls back to the library's own (HIP IPC), and the line says so (rccl_error, gather.fallback) -- a scaling number
+            # with rccl_ranks 0 is still a measurement of the tracing, not of RCCL.
+            err = None
+            try:
+                ones = torch.ones(1, dtype=torch.int32, device="cuda")
+                dist.all_reduce(ones)
+                torch.cuda.synchronize()
+                rccl_ranks = int(ones.item()) if "nccl" in str(dist.get_backend()) else 0
+            except Exception as exc:   # noqa: BLE001
+                err, rccl_ranks = repr(exc), 0
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=ctl)
+            if any(errs):
+                rccl_error = next(e for e in errs if e)
+                data_ok[0] = False
+                rccl_ranks = 0
+                args.gather = "ipc"
+            elif rccl_ranks != world:
                 raise SystemExit(f"bench.py: --gpus {world}, but the RCCL all-reduce over the process group sums to {rccl_ranks} "
                                  f"(backend {dist.get_backend()})")
             if distinct_devices is not None and distinct_devices != world:
@@ -307,7 +355,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         """gather of per-rank radiance at present time (the only inter-GPU traffic) + back into frame order"""
         if world > 1 and args.gather == "ipc":
             if id(tracer) not in ipc_gathers:
-                ipc_gathers[id(tracer)] = pkg.bands.BandGather(tracer, rank, world, dist)
+                ipc_gathers[id(tracer)] = pkg.bands.BandGather(tracer, rank, world, dist, group=ctl)
             ipc_gathers[id(tracer)].gather("color", frame.data_ptr() if rank == 0 else None)
             return
         tracer.download_to_device("color", band_color.data_ptr())
@@ -325,7 +373,11 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
 
     def fence():
         if world > 1:
-            dist.barrier()
+            if data_ok[0]:
+                dist.barrier()
+            else:
+                torch.cuda.synchronize()
+                dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
     per_rank = []   # N > 1: every rank's own rays and elapsed time of the last timed() region
@@ -352,14 +404,10 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         per_rank.clear()
         if world > 1:   # max over ranks of the elapsed time, sum of rays
             mine = [None] * world
-            dist.all_gather_object(mine, {"rank": rank, "rays": int(rays), "elapsed_ms": round(elapsed * 1e3, 4)})
+            dist.all_gather_object(mine, {"rank": rank, "rays": int(rays), "elapsed_ms": round(elapsed * 1e3, 4)}, group=ctl)
             per_rank.extend(mine)
-            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-            r = torch.tensor([rays], dtype=torch.int64, device=coll_dev)
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            rays = int(r.item())
+            elapsed = max(_gather_floats(dist, ctl, world, elapsed))   # the MAX over ranks
+            rays = sum(int(m["rays"]) for m in mine)
         return elapsed, rays, prof, first_iter
 
     def count_tests(tracer, first_iter, steps):
@@ -373,6 +421,24 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         tracer.set_profiling(False, False)
         return counted
 
+    # N > 1: one present over RCCL before anything is timed.  A gather that throws here (on any rank) does not end the run: every
+    # rank switches to the library's gather (--gather ipc: HIP IPC mapping, control messages over the gloo group) and the line
+    # carries the error in gather.fallback -- as the IPC leg below already reports ITS failures beside the RCCL figure.
+    if world > 1 and args.gather == "rccl" and data_ok[0]:
+        err = None
+        try:
+            present(pt)
+            torch.cuda.synchronize()
+        except Exception as exc:   # noqa: BLE001
+            err = repr(exc)
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=ctl)
+        if any(errs):
+            gather_fallback[0] = "the RCCL gather failed before the timed region (%s): the timed region uses --gather ipc" % next(e for e in errs if e)
+            args.gather = "ipc"
+    elif world > 1 and not data_ok[0]:
+        gather_fallback[0] = "RCCL unavailable (%s): the timed region uses --gather ipc, control messages over gloo" % rccl_error
+
     elapsed, rays, prof, first_iter = timed(pt, args.steps, args.warmup)
     last_live = pt.stats()["last_live"]
     ranks_detail = list(per_rank)
@@ -384,21 +450,34 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     gather = None
     if world > 1:
         gather = {"bytes_per_present": int(sum(len(rr) for rr in rank_rows[1:]) * W * 12),
-                  "transport_in_timed_region": args.gather, "backend": "gloo (rehearsal)" if rehearse else "nccl (RCCL)"}
+                  "transport_in_timed_region": args.gather, "backend": "gloo (rehearsal)" if rehearse else "nccl (RCCL)",
+                  "fallback": gather_fallback[0]}
         saved = args.gather
-        args.gather = "rccl"
-        us = []
-        for _ in range(5):
-            fence()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            present(pt)
-            e1.record()
-            torch.cuda.synchronize()
-            us.append(e0.elapsed_time(e1) * 1e3)
-        rccl_frame = frame.clone() if rank == 0 else None
-        gather["rccl_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
-        gather["rccl_note"] = "pack + dist.gather + index_copy into row order, rank 0's stream, median of 5"
+        rccl_frame = None
+        if gather_fallback[0] is None:
+            args.gather = "rccl"
+            us, err = [], None
+            try:
+                for _ in range(5):
+                    fence()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    present(pt)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us.append(e0.elapsed_time(e1) * 1e3)
+            except Exception as exc:   # noqa: BLE001 -- reported; the IPC leg follows
+                err = repr(exc)
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=ctl)
+            if any(errs):
+                gather["rccl_us"], gather["rccl_error"] = None, next(e for e in errs if e)
+            else:
+                rccl_frame = frame.clone() if rank == 0 else None
+                gather["rccl_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 else None
+            gather["rccl_note"] = "pack + dist.gather + index_copy into row order, rank 0's stream, median of 5"
+        else:
+            gather["rccl_us"], gather["rccl_note"] = None, "not measured: " + gather_fallback[0]
         # the library's gather: handles once, then publish / barrier / pull
         try:
             handle, err = (pt.band_export() if rank else b""), None
@@ -413,7 +492,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
             except Exception as exc:   # noqa: BLE001
                 err = "peer-access query failed: " + repr(exc)
         handles = [None] * world
-        dist.all_gather_object(handles, (handle, err))
+        dist.all_gather_object(handles, (handle, err), group=ctl)
         state = [None]
         if rank == 0:
             try:
@@ -423,22 +502,23 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                     pt.band_import(r, handles[r][0])
             except Exception as exc:   # noqa: BLE001
                 state = [repr(exc)]
-        dist.broadcast_object_list(state, src=0)
+        dist.broadcast_object_list(state, src=0, group=ctl)
         if state[0] is None:
             us = []
             for _ in range(5):
                 if rank:
                     pt.band_publish("color")
-                dist.barrier()
+                dist.barrier(group=ctl)
                 if rank == 0:
                     try:
                         pt.gather_frame("color", frame.data_ptr())
                         us.append(pt.gather_last_us())
                     except Exception as exc:   # noqa: BLE001 -- reported in the line, the RCCL figure stands
                         state[0] = repr(exc)
-                dist.barrier()
+                dist.barrier(group=ctl)
             gather["ipc_us"] = round(sorted(us)[len(us) // 2], 1) if rank == 0 and us else None
-            gather["transports_agree"] = bool(torch.equal(rccl_frame, frame)) if rank == 0 and state[0] is None else None   # the same assembled frame, bit for bit
+            gather["transports_agree"] = (bool(torch.equal(rccl_frame, frame)) if rank == 0 and state[0] is None and rccl_frame is not None
+                                          else None)   # the same assembled frame, bit for bit
             if rank == 0 and state[0] is not None:
                 gather["ipc_error"] = state[0]
             gather["ipc_note"] = ("ptc_gather_frame: one kernel on the root reads every rank's band where it lies (HIP IPC "
@@ -468,9 +548,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
     slow_rays = sum(prof["slow_rays"])
     walked_total = roofline["rays_walked_by_the_launches"]
     if world > 1:   # every rank's traversal launches
-        wt = torch.tensor([walked_total], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(wt, op=dist.ReduceOp.SUM)
-        walked_total = int(wt.item())
+        walked_total = int(sum(_gather_floats(dist, ctl, world, walked_total)))
 
     # the tuned schedule on the same workload (only when the timed region above was too short to show it)
     steady = None
@@ -571,7 +649,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
                                       f"{ref['rays']} rays in {dt:.2f} s; oracle/liboracle.so (CPU restatement; the reference has no CPU path)"}
             mine = {"rank": 0, **compare(timed_frames, ref)}
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)   # (the gloo group: its timeout is set for a rank that waits for rank 0's oracle leg, see main)
         if rank != 0:
             share = max(1, min(args.cpu_threads, hw // max(world - 1, 1)))
             ref = orc.render_interleaved(flat, scene.camera, W, H, rank, split, BLOCK_ROWS, rank * W * H, 0, cpu_frames, MB,
@@ -580,7 +658,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         every = [mine]
         if world > 1:
             every = [None] * world
-            dist.all_gather_object(every, mine)
+            dist.all_gather_object(every, mine, group=ctl)
         if rank == 0:
             parity = {"against": "the CPU oracle's rendering of each rank's rows (orc_render_streaming_interleaved: blocks of %d rows dealt over %d "
                                  "ranks, paths numbered per rank, slot_offset = rank * W * H), %d accumulated iterations at %dx%d"
@@ -625,7 +703,7 @@ def run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse):
         "roofline": roofline,
         "gather": gather,
         "ranks": ranks_detail or None,
-        "rccl_ranks": rccl_ranks, "distinct_devices": distinct_devices,
+        "rccl_ranks": rccl_ranks, "distinct_devices": distinct_devices, "rccl_error": rccl_error,
         "parity": parity,
         "steady_state": steady,
         "latency": latency,
@@ -726,10 +804,7 @@ def run_config2(args, pkg, torch, local_rank):
 def run_config5(args, pkg, torch, local_rank):
     """Config 5: 1 spp interactive mode + Edge-Avoiding A-Trous denoise after every frame, 1920x1080."""
     W, H, MB = args.width or 1920, args.height or 1080, args.max_bounces
-    nx, nz = (int(v) for v in args.grid.split("x"))
-    scene = pkg.scenes.heightfield_scene((W, H), nx=nx, nz=nz)
-    flat = scene.build_scene()
-    flat.bvh, bvh_depth = pkg.bvh_from_mesh(list(scene.mesh_map_.values())[0])
+    scene, flat, bvh_depth, _ = config3_scene(pkg, W, H, args.grid)
     P = W * H
     rgba = torch.empty((H, W), dtype=torch.int32, device="cuda")
 
@@ -787,6 +862,27 @@ def run_config5(args, pkg, torch, local_rank):
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "pricing": "(48 B read + 16 B written) per pixel and pass", "launches": prof["denoise_passes"],
                 "avg_launch_us": round(den_ms_pass * 1e3, 2), "alg_bytes_per_launch": pass_bytes}
+    # what binds the kernel, from counters (tools/pmc_denoise.sh -> profiles/pmc_denoise.json; every `pixel` there is one output
+    # pixel of one pass): the HBM pricing stays in achieved / peak / frac
+    den_rec = None
+    try:
+        den_rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_denoise.json")))
+    except Exception:   # noqa: BLE001
+        pass
+    if den_rec is not None and (W, H) == (1920, 1080):
+        raw = den_rec.get("raw_means_per_launch") or {}
+        lds_conf = raw.get("SQ_LDS_BANK_CONFLICT")
+        lds_act = raw.get("SQ_LDS_IDX_ACTIVE") or raw.get("SQ_ACTIVE_INST_LDS")
+        roofline["priced_against"] = "hbm"
+        roofline["bound"] = den_rec.get("bound", "valu-issue")
+        roofline["counters"] = {"valu_pipe_frac": den_rec.get("valu_pipe_frac"), "lanes_per_valu_inst": den_rec.get("lanes_per_valu_inst"),
+                                "valu_inst_per_pixel_and_pass": den_rec.get("valu_inst_per_ray"),
+                                "lds_inst_per_pixel_and_pass": den_rec.get("lds_inst_per_ray"),
+                                "lds_bank_conflict_cycles_over_lds_active": round(lds_conf / lds_act, 4) if lds_conf is not None and lds_act else None,
+                                "wave_occupancy_frac": den_rec.get("wave_occupancy_frac"), "l2_hit_frac": den_rec.get("l2_hit_frac"),
+                                "mean_launch_us_serialised_by_the_profiler": den_rec.get("mean_launch_us_serialised_by_the_profiler"),
+                                "source": den_rec.get("source")}
+        roofline["bound_note"] = den_rec.get("bound_note")
     cpu_baseline = parity = None
     if not args.no_cpu_baseline:
         # the same frame on the host: one iteration, the four A-Trous passes, the tonemap -- timed (cpu_baseline) and compared
@@ -829,14 +925,164 @@ def run_config5(args, pkg, torch, local_rank):
     }
 
 
+def reference_order_gpu(args, pkg, torch, local_rank, frames=3):
+    """The reference's ALGORITHM restated in HIP on this GPU -- not the CUDA build, which cannot run here: one thread per path
+    walking the 32-byte two-child nodes in the reference's order without culling (trace_variant 0 = k_trace,
+    path_tracer.cu:36-76), intersect -> material -> partition as three kernels per bounce (fused_shade 0), every ray in every
+    launch (filter_rays 0, beam 0), one frame at a time (frames_in_flight 1), and the live count read back by the host after
+    every bounce (ptc_read_live_count: the reference's thrust result, path_tracer.cu:454-457).  Same scene, resolution,
+    bounce cap and ray definition as the headline; the denominator for "x times the reference's way of doing it" on the
+    same silicon."""
+    W, H, MB = args.width or 1920, args.height or 1080, args.max_bounces
+    scene, flat, _, _ = config3_scene(pkg, W, H, args.grid)
+
+    def tracer(reference_order):
+        pt = pkg.PathTracer(device=local_rank, max_bounces=MB)
+        if reference_order:
+            pt.set_param("frames_in_flight", 1)
+            pt.set_param("batch_frames", 1)
+            pt.set_trace_variant(0)
+            for name in ("fused_shade", "filter_rays", "beam"):
+                pt.set_param(name, 0)
+        pt.create_buffers((W, H), flat)
+        pt.set_stream(torch.cuda.current_stream().cuda_stream)
+        pt.max_iterations = 1 << 30
+        return pt
+
+    def frame(pt):
+        pt.trace_begin(scene.camera)
+        n, rays = W * H, 0
+        for b in range(MB):
+            if n == 0:                     # path_tracer.cu:418: the loop ends with the last live path
+                break
+            rays += n
+            pt.trace_bounce(b)
+            n = pt.read_live_count(b + 1)  # host read-back per bounce, as the reference's partition result
+        pt.trace_end()
+        return rays
+
+    pt = tracer(True)
+    frame(pt)
+    pt.synchronize()
+    t0 = time.perf_counter()
+    rays = sum(frame(pt) for _ in range(frames))
+    pt.synchronize()
+    dt = time.perf_counter() - t0
+    # its frames against the default schedule's (which the parity leg of this line holds against the oracle)
+    pt.restart()
+    for _ in range(2):
+        frame(pt)
+    got = {k: pt.download(k) for k in ("color", "normal", "depth")}
+    pt.close()
+    with tracer(False) as dp:
+        for _ in range(2):
+            dp.path_trace(scene.camera)
+        want = {k: dp.download(k) for k in ("color", "normal", "depth")}
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "frames": frames, "ms_per_frame": round(dt / frames * 1e3, 3),
+            "rays": int(rays),
+            "what": "the reference's algorithm restated in HIP on this GPU -- NOT the CUDA build: one thread per path, 32-byte "
+                    "two-child nodes in the reference's order, no culling (trace_variant 0), three kernels per bounce "
+                    "(fused_shade 0), every ray in every launch (filter_rays 0, beam 0), one frame in flight, live count read "
+                    "back by the host after every bounce (path_tracer.cu:36-76,413-458)",
+            "equals_default_schedule_bit_for_bit": bool(all(np.array_equal(got[k], want[k]) for k in got))}
+
+
+def extra_legs(args, pkg, torch, dist, local_rank, line):
+    """What only builder-run logs showed until round 5, attached to the driver's line (N = 1, config 3; --no-extras skips it):
+    other_configs (config 2 and config 5 with their parity), rank_share (rank 0's rows of a 2 / 4 / 8-way split traced alone
+    on this GPU with the schedule such a run would pick, parity against the oracle's rendering of those rows),
+    scaling_projection (what rank_share predicts for --gpus N before any gather or barrier) and reference_order_gpu."""
+    import copy
+
+    def sub(**over):
+        a = copy.copy(args)
+        a.param = list(args.param)
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+
+    t_begin = time.perf_counter()
+    out = {}
+    shares = {}
+    whole_ms = line["ms_per_step"] * args.steps
+    for n in (2, 4, 8):
+        l = run_config3(sub(share_of=n, no_extras=True, cpu_frames=min(args.cpu_frames, 2)), pkg, torch, dist, 1, 0, local_rank, False)
+        ms = l["ms_per_step"] * args.steps
+        shares[str(n)] = {"ms_per_%d_steps" % args.steps: round(ms, 4), "whole_frame_over_share": round(whole_ms / ms, 3),
+                          "mrays_per_s_of_the_rank": l["value"], "frames_per_launch": l["config"]["frames_per_launch"],
+                          "frames_in_flight": l["config"]["frames_in_flight"],
+                          "parity_bit_exact": (l.get("parity") or {}).get("bit_exact")}
+    out["rank_share"] = {"what": "rank 0's rows of an N-way split (blocks of %d rows round-robin) traced alone on this GPU with the "
+                                 "schedule a --gpus N run picks; no gather, no barrier; parity = those rows against the CPU oracle's "
+                                 "rendering of that rank" % BLOCK_ROWS,
+                         "whole_frame_ms_per_%d_steps" % args.steps: round(whole_ms, 4), "by_ranks": shares}
+    rays_job = line["config"]["rays_per_step"] * args.steps
+    out["scaling_projection"] = {
+        "what": "a one-GPU projection of --gpus N, to read a measured SCALE value against: the job's rays / rank 0's time for its "
+                "share (interleaved blocks make the ranks' shares alike to a few percent); the present-time gather (%.1f MB into rank 0, "
+                "tens of microseconds over xGMI) and two barriers come on top" % (1920 * 1080 * 12 * 7 / 8 / 1e6),
+        "by_gpus": {k: {"predicted_mrays_per_s": round(rays_job / (v["ms_per_%d_steps" % args.steps] * 1e-3) / 1e6, 1),
+                        "predicted_speedup": v["whole_frame_over_share"],
+                        "schedule": "%d x %d frames, %d persistent wavefronts" % (v["frames_in_flight"] // max(v["frames_per_launch"], 1),
+                                                                                 v["frames_per_launch"], 5120 if int(k) <= 2 else 2560)}
+                    for k, v in shares.items()}}
+    out["reference_order_gpu"] = reference_order_gpu(args, pkg, torch, local_rank)
+    ref = out["reference_order_gpu"]["value"]
+    out["vs_reference_order_gpu"] = {"ratio": round(line["value"] / ref, 2) if ref else None,
+                                     "note": "value / reference_order_gpu.value: this library's schedule against the reference's "
+                                             "algorithm restated in HIP on the same GPU (not the CUDA build)"}
+    c2 = run_config2(sub(config=2, steps=64, warmup=32, width=0, height=0, cpu_frames=min(args.cpu_frames, 2), batch_frames=0, streams=0,
+                         param=[]), pkg, torch, local_rank)
+    c5 = run_config5(sub(config=5, steps=32, warmup=8, param=[]), pkg, torch, local_rank)
+    out["other_configs"] = {
+        "config2": {"value": c2["value"], "unit": c2["unit"], "steps": 64, "ms_per_step": c2["ms_per_step"],
+                    "frame_level_frac": c2["roofline"].get("frame_level_frac"), "kernel_frac": c2["roofline"]["frac"],
+                    "parity": {k: (c2.get("parity") or {}).get(k) for k in ("bit_exact", "live_equal", "rays_equal", "mse")},
+                    "workload": c2["config"]["workload"]},
+        "config5": {"ms_per_frame": c5["value"], "unit": c5["unit"], "steps": 32,
+                    "denoise_ms_per_pass": c5["config"]["denoise_ms_per_pass"], "denoise_bound": c5["roofline"]["bound"],
+                    "ms_per_frame_without_denoise": c5["config"]["ms_per_frame_without_denoise"],
+                    "parity": {k: (c5.get("parity") or {}).get(k) for k in ("bit_exact", "live_equal", "denoised_within_tolerance",
+                                                                              "denoised_max_abs_err", "rgba_max_lsb")},
+                    "workload": c5["config"]["workload"]}}
+    out["extra_legs_s"] = round(time.perf_counter() - t_begin, 2)
+    return out
+
+
+def count_gpus_without_touching_them():
+    """GPUs this process could use, counted WITHOUT starting a GPU runtime here (the parent of the ranks must stay clean: it
+    spawns the launcher).  A short-lived child asks the library (ptc_device_count: hipGetDeviceCount, which honours
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES); if that child cannot run, the KFD topology is read instead (nodes with
+    SIMDs are GPUs)."""
+    import subprocess
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); n = ctypes.c_int(0); "
+            "rc = lib.ptc_device_count(ctypes.byref(n)); print(n.value if rc == 0 else 0)")
+    try:
+        out = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "cuda-path-tracer_amd", "libptcore.so")],
+                             capture_output=True, text=True, timeout=120)
+        if out.returncode == 0:
+            return int(out.stdout.strip().splitlines()[-1])
+    except Exception:   # noqa: BLE001
+        pass
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        pass
+    return n
+
+
 def spawn_ranks(args):
     """`bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run, N ranks on this
-    node, as a CHILD process (this one has not initialised HIP: torch.cuda.device_count() does not), and hand its exit
-    code on.  The ranks print the JSON line themselves (rank 0)."""
+    node, as a CHILD process (this one never initialises HIP: the devices are counted by a short-lived child), and hand
+    its exit code on.  The ranks print the JSON line themselves (rank 0)."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    have = count_gpus_without_touching_them()
     if have < args.gpus and not args.rehearse_on_one_gpu:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s); pass --rehearse-on-one-gpu to run "
                          f"the {args.gpus}-rank code path on one device (not a scaling measurement)\n")
@@ -871,15 +1117,23 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    ctl = None
     if world > 1:
+        import datetime
+        long_wait = datetime.timedelta(minutes=30)   # ranks wait at a barrier while rank 0 renders its oracle rows (seconds; never minutes)
         if rehearse:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=long_wait)
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=long_wait)
+            # control plane: handles, flags, per-rank figures and the barriers outside the data path travel over gloo, so that
+            # a failing RCCL call can be reported and worked around instead of ending (or hanging) the run
+            ctl = dist.new_group(backend="gloo", timeout=long_wait)
 
     pkg = graft.load_package()
     if args.config == 3:
-        line = run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse)
+        line = run_config3(args, pkg, torch, dist, world, rank, local_rank, rehearse, ctl)
+        if line is not None and world == 1 and args.share_of <= 1 and not args.no_extras:
+            line.update(extra_legs(args, pkg, torch, dist, local_rank, line))
     elif args.config == 2:
         line = run_config2(args, pkg, torch, local_rank)
     else:
@@ -887,7 +1141,7 @@ def main():
     if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=ctl)
         dist.destroy_process_group()
 
 

@@ -99,11 +99,13 @@ class BandGather:
     inter-process memory, device-to-device copies into the root; xGMI between GPUs).  `dist` carries the handles
     (once) and the "rows are published" barrier (every present)."""
 
-    def __init__(self, path_tracer, rank, world, dist):
-        self.pt, self.rank, self.world, self.dist = path_tracer, rank, world, dist
+    def __init__(self, path_tracer, rank, world, dist, group=None):
+        """group: the process group the handles and barriers travel over (None = the default one; bench.py passes its gloo
+        control group so that this gather still works where RCCL does not)"""
+        self.pt, self.rank, self.world, self.dist, self.group = path_tracer, rank, world, dist, group
         if world > 1:
             handles = [None] * world
-            dist.all_gather_object(handles, path_tracer.band_export() if rank else b"")
+            dist.all_gather_object(handles, path_tracer.band_export() if rank else b"", group=group)
             if rank == 0:
                 for r in range(1, world):
                     path_tracer.band_import(r, handles[r])
@@ -113,8 +115,8 @@ class BandGather:
         if self.world > 1:
             if self.rank:
                 self.pt.band_publish(which)
-            self.dist.barrier()
+            self.dist.barrier(group=self.group)
         out = self.pt.gather_frame(which, dev_ptr) if self.rank == 0 else None
         if self.world > 1:
-            self.dist.barrier()   # nobody overwrites its exported rows before the root has pulled them
+            self.dist.barrier(group=self.group)   # nobody overwrites its exported rows before the root has pulled them
         return out
