@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PTCORE_LIB: development hook for A/B runs of differently compiled libraries (tools/ab.sh); always a libptcore build
+# PTCORE_LIB: development hook for A/B runs of differently compiled libraries (tools/ab.py); always a libptcore build
 LIB_PATH = os.environ.get("PTCORE_LIB") or os.path.join(_HERE, "libptcore.so")
 
 PTC_MAX_BOUNCES_CAP = 64
