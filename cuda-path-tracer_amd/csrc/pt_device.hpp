@@ -32,6 +32,7 @@ static_assert(kLds4 >= 4 && kLds4 <= kStackDepth, "PT_T4_LDS out of range");
 // error bits in DeviceCounters::flags
 constexpr uint32_t kFlagStackOverflow = 1u;
 constexpr uint32_t kFlagDispatchOrder = 2u;  // k_shade_fused gave up waiting for a predecessor tile (bounded look-back wait)
+constexpr uint32_t kFlagPersistStall = 4u;   // k_persist: a wavefront waited for work (or for the redo lock) beyond the bound and gave up
 
 // Same 160-byte layout as ptc_object / the reference's GPUObject (scene.hpp:16-22)
 struct DObject {
@@ -240,6 +241,45 @@ struct DCameras {
   DCamera c[kMaxBatch];
 };
 
+// ---- the bounce-spanning persistent launch (k_persist, round 5) ------------------------------------
+// One launch per batch carries the traversal of bounces >= 1 and the shade passes of ALL bounces: of every five wavefronts
+// four walk rays (traverse4_walk<.., kPersist>) and one shades tiles (shade_tile<.., 1, true>).  Frame f moves through
+//   S(0) -> T(1) -> S(1) -> T(2) -> ... -> S(max_bounces - 1) -> done          (R(b): the exact redo, between T(b) and S(b))
+// on its own; what a frame is in is one 64-bit word (phase code << 32 | count: rays of a T phase, tiles of an S phase)
+// that the wavefront finishing the phase's last piece of work rewrites, and everybody else polls.  All of it through
+// agent-scope atomics; the payload (hit records, path state) is stored write-through and loaded past the L1 (sc1).
+constexpr uint32_t kPersistSlotBits = 26u;  // a lane's ray: position in the batch (frame * stride + slot) | frame << 26
+constexpr uint32_t kPersistSlotMask = (1u << kPersistSlotBits) - 1u;
+constexpr uint32_t kPersistDyn = 128u;      // rays per cursor add (fixed: a cursor then only ever stands on multiples of it)
+constexpr uint32_t kPhaseT = 0u, kPhaseRedo = 1u, kPhaseRedoing = 2u, kPhaseS = 3u, kPhaseDone = 0xffffffffu;  // code = bounce << 2 | kind
+struct DPersistFrame {       // every hot word on a 128-byte line of its own
+  uint32_t cursor[8][32];    // [region][0]: bounce << 26 | rays of the frame's current T phase handed out from that region
+  uint32_t t_done[32];       // [0]: rays of the current T phase whose results are in memory
+  uint32_t s_ticket[32];     // [0]: bounce << 26 | next tile of the current S phase
+  uint32_t s_done[32];       // [0]: tiles of the current S phase finished
+};
+struct DPersist {
+  unsigned long long state[kMaxBatch];  // two lines, read by everybody
+  uint32_t started, frames_done, redo_lock, error;
+  uint32_t pad[28];
+  DPersistFrame f[kMaxBatch];
+};
+struct DPersistArgs {
+  DPersist* st;
+  DPaths paths[2];           // bounce b reads paths[b & 1] and writes paths[(b & 1) ^ 1]
+  int max_bounces;
+  uint32_t service_every;    // one wavefront in this many (by arrival) is a service wavefront
+  uint32_t tail_begin, tail_end;  // the sphere run that ends the object list (k_shade_fused's obj_begin / obj_end)
+  int staged;
+  const uint32_t* slot_base;
+  unsigned long long* tile_desc;
+  uint32_t tile_stride, epoch0;   // bounce b's shade pass carries epoch0 + b
+  DFrame stage;
+  DBand band;
+  const uint32_t* list0;     // bounce 0: the work list k_raygen left when it finished the other primaries itself, or null
+  uint32_t* slow_list;       // per frame at f * stride (DeviceCounters::slow_count of that frame)
+};
+
 struct DDenoise {
   float c_phi, n_phi, p_phi;
   int variant;  // 0: taps staged in LDS per sub-lattice (k_denoise_lds, default); 1: taps through L1 / L2 (k_denoise)
@@ -337,6 +377,11 @@ void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, 
                         DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list = nullptr);
 uint32_t shade_tiles_per_frame(uint32_t max_paths);
 void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi);
+// the bounce-spanning persistent launch (pt_kernels.hip, k_persist): state set-up (k_persist_init) + the launch, `waves` wavefronts;
+// spheres: the object list ends in a sphere run (pa.tail_begin / tail_end); listed0: bounce 0's shade pass walks pa.list0
+void launch_persist(hipStream_t s, const DScene& scene, uint32_t obj_index, DHits hits, DeviceCounters* counters, const DBatchInfo& bi,
+                    const DPersistArgs& pa, uint32_t waves, bool spheres, bool listed0);
+uint32_t persist_tiles_per_frame(uint32_t max_paths);
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters);
 void launch_preview(hipStream_t s, const float4* buf, uint32_t pix_count, int mode, uint32_t* rgba);

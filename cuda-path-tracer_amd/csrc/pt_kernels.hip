@@ -35,6 +35,7 @@ static_assert(pt::feed_rules::kBatch == (uint32_t)pt::kWave, "a feed batch is on
 namespace pt {
 
 #include "pt_kernels_common.inc"
+#include "pt_shade_tile.inc"  // (the persistent launch's service wavefronts shade tiles: k_persist below)
 
 // intersection_kernel, path_tracer.cu:271-290.  One wavefront per 64-path chunk.
 template <bool kCount>
@@ -218,6 +219,102 @@ struct BatchFeed {
   }
 };
 
+// The feed of the bounce-spanning persistent launch (k_persist; DPersist in pt_device.hpp): the rays of frame f's current
+// traversal phase T(b) -- live[b] rays, cut into the same eight interleaved regions as a launch's (pt_feed_rules.hpp) -- are
+// handed out kPersistDyn at a time from one cursor per region; frames are dealt IN ORDER (the lowest frame that has rays
+// left in this wavefront's region first, other regions after that), so that frame f's bounce is complete -- and its shade
+// pass, and then its next bounce, can start -- while later frames are still being dealt.
+// A cursor carries its phase (bounce << 26): a wavefront that decided on stale knowledge of a frame still gets, from its
+// add, a range of the frame's CURRENT phase and the tag to tell -- it then re-reads the frame's state and goes on with that
+// (the add cannot be undone, and it need not be: the rays it stands for exist and nobody else will be given them).
+struct PersistFeed {
+  DPersist* st;
+  uint32_t stride, count, home_r;
+  bool have;                              // (cf, cr) below is a frame / region this wavefront last found rays in
+  uint32_t cf, cr, cbounce, cn, crs, clen;
+  __device__ __forceinline__ void init(DPersist* st_, const DBatchInfo& bi, uint32_t region)
+  {
+    st = st_;
+    stride = bi.stride;
+    count = bi.count;
+    home_r = region & 7u;
+    have = false;
+    cf = cr = cbounce = cn = crs = clen = 0u;
+  }
+  __device__ __forceinline__ void set_geometry(uint32_t n)
+  {
+    cn = n;
+    crs = feed_rules::region_size_of(n);
+    clen = feed_rules::region_len_of(n, crs, cr);
+  }
+  // wave-uniform.  1: [begin, end) are batch positions (frame * stride + slot) of rays of `frame` entering `bounce`;
+  // 0: nothing to hand out right now (frames are between phases, or all rays of the running phases are out);
+  // -1: every frame of the batch is done
+  __device__ __forceinline__ int acquire(uint32_t& begin, uint32_t& end, uint32_t& frame, uint32_t& bounce)
+  {
+    for (int round = 0; round < 6; ++round) {
+      if (have) {
+        uint32_t old = 0u;
+        if (threadIdx.x == 0u) old = __hip_atomic_fetch_add(&st->f[cf].cursor[cr][0], kPersistDyn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        const uint32_t tag = old >> kPersistSlotBits, base = old & kPersistSlotMask;
+        if (tag != cbounce) {  // the frame has moved on since this wavefront looked: the range is one of its current phase
+          const unsigned long long now = __hip_atomic_load(&st->state[cf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cbounce = tag;
+          set_geometry((uint32_t)now);
+          if ((uint32_t)(now >> 32) != ((tag << 2) | kPhaseT)) {  // cannot be: a T phase does not end before its rays are handed out
+            if (threadIdx.x == 0u) __hip_atomic_fetch_or(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have = false;
+            return -1;
+          }
+        }
+        if (base < clen) {
+          begin = cf * stride + feed_rules::pos_of(crs, cr, base);
+          end = begin + (min(clen, base + kPersistDyn) - base);
+          frame = cf;
+          bounce = cbounce;
+          return 1;
+        }
+        have = false;
+      }
+      // every frame's state at once (lanes 0..31 and 32..63 both hold frame lane & 31: two regions are probed per step)
+      const uint32_t f = threadIdx.x & 31u, half = threadIdx.x >> 5;
+      unsigned long long s = (unsigned long long)kPhaseDone << 32;
+      if (f < count) s = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t code = (uint32_t)(s >> 32), n = (uint32_t)s;
+      if (__ballot(code != kPhaseDone) == 0ull) return -1;
+      const bool is_t = code != kPhaseDone && (code & 3u) == kPhaseT;
+      if (__ballot(is_t) == 0ull) return 0;
+      const uint32_t rs = feed_rules::region_size_of(n);
+      bool found = false;
+      for (uint32_t dr = 0u; dr < 8u && !found; dr += 2u) {
+        const uint32_t r = (home_r + dr + half) & 7u;
+        const uint32_t len = is_t ? feed_rules::region_len_of(n, rs, r) : 0u;
+        bool has = false;
+        if (len != 0u) {
+          const uint32_t c = __hip_atomic_load(&st->f[f].cursor[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          has = (c >> kPersistSlotBits) == (code >> 2) && (c & kPersistSlotMask) < len;
+        }
+        const uint64_t m = __ballot(has);
+        if (m != 0ull) {
+          // the lowest frame; of its two probed regions the nearer one
+          const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+          const int flo = lo ? __ffs((int)lo) - 1 : 64, fhi = hi ? __ffs((int)hi) - 1 : 64;
+          const int sel = flo <= fhi ? flo : fhi + 32;
+          cf = (uint32_t)sel & 31u;
+          cr = (home_r + dr + ((uint32_t)sel >> 5)) & 7u;
+          cbounce = (uint32_t)__builtin_amdgcn_readlane((int)(code >> 2), sel);
+          set_geometry((uint32_t)__builtin_amdgcn_readlane((int)n, sel));
+          have = true;
+          found = true;
+        }
+      }
+      if (!found) return 0;
+    }
+    return 0;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // variant 3 (default): persistent wavefronts over the four-wide collapse, 64-byte quantised nodes
 // ------------------------------------------------------------------------------------------------
@@ -293,11 +390,46 @@ __device__ __forceinline__ void set_aside(DeviceCounters* counters, uint32_t* sl
   __hip_atomic_store(&slow_list[at], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool kCount, bool kFirst, bool kBeam>
+// sc1 forms of the hand-over stores and loads of the persistent launch (kPersist below): write-through / past the L1, so
+// that a wavefront on another XCD sees them (MI355X_MICROARCH.md, inter-workgroup visibility).  Hand-issued: the compiler
+// does not count them, which can only make one of its own waits longer; the loads carry their wait.
+__device__ __forceinline__ void st_sc1(float4* p, const float4 v)
+{
+  v4f w;
+  w.x = v.x;
+  w.y = v.y;
+  w.z = v.z;
+  w.w = v.w;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void ld2_sc1(const float4* pa, const float4* pb, float4& a, float4& b)
+{
+  v4f x, y;
+  asm volatile(
+      "global_load_dwordx4 %0, %2, off sc1\n\t"
+      "global_load_dwordx4 %1, %3, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(x), "=&v"(y)
+      : "v"(pa), "v"(pb)
+      : "memory");
+  a = make_float4(x.x, x.y, x.z, x.w);
+  b = make_float4(y.x, y.y, y.z, y.w);
+}
+
+// kPersist (k_persist, round 5): the wavefront does not belong to one bounce's launch but lives for the whole batch -- its
+// rays come from PersistFeed (frame f's bounce b as soon as the shade pass of (f, b - 1) is done), a lane's `slot` carries
+// its frame in the top bits, finished rays are counted per frame (in LDS, then on the frame's counter once their hit
+// records are in memory), and when nothing can be handed out the wavefront finishes what it holds (the second loop),
+// waits, and starts over.  `paths` / `bounce` / `work_slot` / `order` / `listed` are unused then (pa->paths[bounce & 1]).
+template <bool kCount, bool kFirst, bool kBeam, bool kPersist = false>
 __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
                                                int bounce, int work_slot, DeviceCounters* counters, uint32_t* slow_list,
-                                               const uint32_t* order, const DBatchInfo& bi, const bool listed)
+                                               const uint32_t* order, const DBatchInfo& bi, const bool listed,
+                                               const DPersistArgs* pa = nullptr)
 {
+  static_assert(!kPersist || (kFirst && !kBeam && !kCount), "the persistent launch: one mesh object per bounce, bounces >= 1, not instrumented");
+  constexpr uint32_t kSlotMask = kPersist ? kPersistSlotMask : 0xffffffffu;
+  __shared__ uint32_t s_pend[kPersist ? kMaxBatch : 1];  // kPersist: finished rays per frame, not yet on the frame's counter
   __shared__ uint32_t s_stack[kLds4 * kWave];
   // work splitting at the end of a launch (see `split` below): per lane = per ray group led by that lane
   __shared__ unsigned long long s_grp_best[kWave];  // best candidate of the group so far: t bits << 32 | ~triangle
@@ -311,13 +443,15 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   // `slot` below is batch-global (frame * bi.stride + slot in the frame); flags, the slow-ray list and the
   // test tallies of the whole batch go to frame 0's counters
   uint32_t n_max = 0u;
-  for (uint32_t f = 0; f < bi.count; ++f) n_max = max(n_max, listed ? counters[f].list_count : counters[f].live[bounce]);
-  if (n_max == 0u) return;
+  if (!kPersist) {
+    for (uint32_t f = 0; f < bi.count; ++f) n_max = max(n_max, listed ? counters[f].list_count : counters[f].live[bounce]);
+    if (n_max == 0u) return;
+  }
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const float4* tris = sc.tris + kTriVec4 * (size_t)sc.object_tri_base[obj_index];
   // more wavefronts than batches (the margin keeps every wavefront that owns a static batch, see BatchFeed)
-  if (blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
+  if (!kPersist && blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
   // the object's world box: the same for every ray of the launch (scalar registers)
   auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
   const f3 obj_bmin = mk3(uni(obj->bmin[0]), uni(obj->bmin[1]), uni(obj->bmin[2]));
@@ -329,8 +463,16 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   unsigned long long tp_c_split = 0ull, tp_c_retire = 0ull, tp_c_step = 0ull, tp_lanes_tail = 0ull;
 #endif
   BatchFeed feed;
-  feed.init(counters, bi, bounce, work_slot, sc.static_eighths, listed);
+  PersistFeed pfeed;
+  if (kPersist) {
+    pfeed.init(pa->st, bi, blockIdx.x);
+    if (threadIdx.x < (uint32_t)kMaxBatch) s_pend[threadIdx.x] = 0u;
+  } else {
+    feed.init(counters, bi, bounce, work_slot, sc.static_eighths, listed);
+  }
   uint32_t priv_next = 0u, priv_end = 0u;
+  uint32_t cur_frame = 0u, cur_bounce = 0u;  // kPersist: whose rays [priv_next, priv_end) are
+  bool dry = false;                           // kPersist: the feed had nothing to hand out when last asked
 
   bool active = false;
   bool pending = false;
@@ -398,7 +540,8 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           float en, ef;
           if (!slab_exact(xyz(pb0), xyz(pb1), oo, od, en, ef) || sc.force_slow == 2u) {
             // a ray grazing the parent's box within rounding: redone with exact box decisions by the launch's epilogue (redo_slow_rays)
-            set_aside(counters, slow_list, slot);
+            if (kPersist) set_aside(counters + (slot >> kPersistSlotBits), pa->slow_list + (size_t)(slot >> kPersistSlotBits) * bi.stride, slot & kSlotMask);
+            else set_aside(counters, slow_list, slot);
             best_k = -2;
           }
         }
@@ -409,12 +552,46 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       const f3 p = ro + rd * best_t;
       const uint32_t side = dot(rd, outward) < 0.0f ? 0u : 1u;
       const f3 nn = side == 0u ? outward : -outward;
-      stnt(&hits.tp[slot], make_float4(best_t, p.x, p.y, p.z));
-      stnt(&hits.nm[slot], make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31))));
+      if (kPersist) {
+        st_sc1(&hits.tp[slot & kSlotMask], make_float4(best_t, p.x, p.y, p.z));
+        st_sc1(&hits.nm[slot & kSlotMask], make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31))));
+      } else {
+        stnt(&hits.tp[slot], make_float4(best_t, p.x, p.y, p.z));
+        stnt(&hits.nm[slot], make_float4(nn.x, nn.y, nn.z, __uint_as_float(mat | (side << 31))));
+      }
     } else if (kFirst && best_k == -1) {
-      stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
+      if (kPersist) st_sc1(&hits.tp[slot & kSlotMask], make_float4(-1.0f, 0.f, 0.f, 0.f));
+      else stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
     }
     if (kCount) atomicMax(&counters->max_box_tests[bounce], ray_boxes);
+    // (kPersist: one more ray of its frame is done -- counted here, added to the frame's counter by flush_done once the
+    // stores above have landed)
+    if (kPersist) __hip_atomic_fetch_add(&s_pend[slot >> kPersistSlotBits], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // kPersist: what this wavefront has finished since the last call goes onto the frames' counters; the lane whose add
+  // completes a frame's traversal phase opens the phase behind it (the exact redo if rays were set aside, else the shade pass)
+  auto flush_done = [&]() {
+    if (!kPersist) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the hit records of what is counted are in memory (sc1 stores)
+    uint32_t v = 0u;
+    if (threadIdx.x < bi.count) v = s_pend[threadIdx.x];
+    if (v != 0u) {
+      const uint32_t f = threadIdx.x;
+      s_pend[f] = 0u;
+      DPersist* st = pa->st;
+      const uint32_t old = __hip_atomic_fetch_add(&st->f[f].t_done[0], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long now = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t n = (uint32_t)now, b = (uint32_t)(now >> 32) >> 2;
+      if (old + v == n) {
+        const uint32_t slow = __hip_atomic_load(&counters[f].slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tiles = (n + kServiceTile - 1u) / kServiceTile;
+        __hip_atomic_store(&st->f[f].s_ticket[0], b << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->f[f].s_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&st->state[f], ((unsigned long long)((b << 2) | (slow ? kPhaseRedo : kPhaseS)) << 32) | tiles, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   };
 
   // ---- work splitting: the tail of a launch -------------------------------------------------------------------
@@ -678,27 +855,41 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     }
   };
 
+  for (;;) {  // kPersist: (first loop, second loop, wait) until every frame of the batch is done; else one pass
   for (;;) {
     const uint64_t idle_mask = __ballot(!active);
     const uint32_t idle = (uint32_t)__popcll(idle_mask);
-    const bool more = priv_next < priv_end || !feed.exhausted();
+    const bool more = priv_next < priv_end || (kPersist ? !dry : !feed.exhausted());
 #ifdef PT_TAILPROF
     ++tp_iters;
 #endif
     if (!more) break;  // nothing left to fetch: the lanes still walking finish in the second loop
     if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
+      flush_done();  // (what the previous refill finished: its stores have had a step's wait to land)
       if (pending) {
         finalize();  // (no ray is shared between lanes before the second loop)
         pending = false;
       }
-      if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
+      if (kPersist) {
+        if (priv_next >= priv_end && pfeed.acquire(priv_next, priv_end, cur_frame, cur_bounce) <= 0) {
+          priv_next = priv_end = 0u;
+          dry = true;
+        }
+      } else if (priv_next >= priv_end && !feed.acquire(priv_next, priv_end)) priv_next = priv_end = 0u;
       const uint32_t mine = priv_next + rank_below(idle_mask);
       const uint32_t range_end = priv_end;
       priv_next = min(priv_end, priv_next + idle);
       if (!active && mine < range_end) {
-        slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
-        const float4 o4 = ldnt(&paths.o4[slot]);
-        const float4 d4 = ldnt(&paths.d4[slot]);
+        float4 o4, d4;
+        if (kPersist) {
+          slot = mine | (cur_frame << kPersistSlotBits);
+          const DPaths& pin = pa->paths[cur_bounce & 1u];
+          ld2_sc1(&pin.o4[mine], &pin.d4[mine], o4, d4);
+        } else {
+          slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
+          o4 = ldnt(&paths.o4[slot]);
+          d4 = ldnt(&paths.d4[slot]);
+        }
         // entry points (DBeam): the tile's four boxes, requested together with the ray -- at bounce 0 the slot says which
         // pixel the ray belongs to, so the address does not wait for the ray (one round trip for both; the first version
         // took the pixel from the loaded ray and paid a second one, in front of every lane of the wavefront)
@@ -750,7 +941,8 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
                                sc.force_slow == 1u, 0)) {
             // degenerate direction (0/0 or overflow in the slab terms voids the error bound): set aside for
             // the launch's epilogue (redo_slow_rays), which takes every box decision with the reference's own test
-            set_aside(counters, slow_list, slot);
+            if (kPersist) set_aside(counters + cur_frame, pa->slow_list + (size_t)cur_frame * bi.stride, slot & kSlotMask);
+            else set_aside(counters, slow_list, slot);
             wrote = true;
             go = false;
           } else {
@@ -805,7 +997,10 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
           }
         }
         if (go) active = true;
-        else if (kFirst && !wrote) stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
+        else if (kPersist) {
+          if (!wrote) st_sc1(&hits.tp[slot & kSlotMask], make_float4(-1.0f, 0.f, 0.f, 0.f));
+          __hip_atomic_fetch_add(&s_pend[cur_frame], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (done without a walk)
+        } else if (kFirst && !wrote) stnt(&hits.tp[slot], make_float4(-1.0f, 0.f, 0.f, 0.f));
       }
     }
     if (__ballot(active) == 0ull) continue;
@@ -865,6 +1060,34 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
 #ifdef PT_TAILPROF
     tp_c_step += clock64() - c2;
 #endif
+  }
+  if (!kPersist) break;
+  // kPersist: this wavefront holds nothing any more.  Its counts go out, then it waits for rays: the feed is asked again
+  // every few hundred cycles (one load of the frames' state words when there is nothing), with a bound -- a wavefront that
+  // has waited about two seconds sets the launch's error word and leaves (everybody does, then: the host reports it).
+  split_mode = false;
+  since_split = since_retire = 0u;
+  flush_done();
+  int got = 0;
+  for (uint32_t spins = 0u;; ++spins) {
+    got = pfeed.acquire(priv_next, priv_end, cur_frame, cur_bounce);
+    if (got != 0) break;
+    __builtin_amdgcn_s_sleep(20);
+    if ((spins & 255u) == 255u && __hip_atomic_load(&pa->st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      got = -1;
+      break;
+    }
+    if (spins > (1u << 22)) {
+      if (threadIdx.x == 0u) {
+        __hip_atomic_fetch_or(&pa->st->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(&counters->flags, kFlagPersistStall);
+      }
+      got = -1;
+      break;
+    }
+  }
+  if (got < 0) break;
+  dry = false;
   }
 #ifdef PT_TAILPROF
   if (threadIdx.x == 0u && blockIdx.x < 8192u && bounce < 16) {
@@ -992,6 +1215,218 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
   const uint32_t count = __hip_atomic_load(&counters->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (count != 0u) redo_slow_rays<kFirst>(sc, obj_index, paths, hits, slow_list, count, counters);
   launch_epilogue(counters, bounce, work_slot, count, bi, listed != 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the bounce-spanning persistent launch (round 5; DESIGN section 4d, DPersist in pt_device.hpp)
+// ------------------------------------------------------------------------------------------------
+// What the per-bounce launches lose (review of round 4): every traversal launch drains the chip on its longest rays, and the
+// streaming kernels between two launches run with no traversal beside them.  Here ONE launch per batch carries the
+// traversal of bounces >= 1 and the shade passes of all bounces (bounce 0's traversal keeps its own launch: entry points,
+// work list).  Of every `service_every` wavefronts (by arrival: whoever runs takes the next role, nothing is assigned to a
+// wavefront that may not be resident) one is a SERVICE wavefront -- it shades tiles of whichever frame's traversal phase is
+// complete, lowest frame first (shade_tile<.., 1, true>: k_shade_fused's tile for one wavefront) and runs the exact redo of
+// set-aside rays -- and the others WALK: traverse4_walk<.., kPersist> over PersistFeed.
+// Forward progress: a walking wavefront waits for nothing but rays to hand out; a shading wavefront waits (in the look-back
+// of its tile) only for tiles with lower tickets, which running wavefronts hold; T(f, b) needs S(f, b - 1), which needs
+// T(f, b - 1): a chain that starts at S(f, 0), ready when the launch starts.  Any five running wavefronts contain both
+// roles, so the launch ends however few of its wavefronts the chip admits at a time.  Every wait is bounded all the same.
+template <bool kSpheres>
+__device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t obj_index, const DPersistArgs& pa, const DHits& hits,
+                                                DeviceCounters* counters, const DBatchInfo& bi)
+{
+  __shared__ uint32_t s_cnt[kFuseK];
+  __shared__ uint32_t s_excl;
+  DPersist* st = pa.st;
+  const uint32_t lane = threadIdx.x, f = lane & 31u;
+  uint32_t spins = 0u;
+  for (;;) {
+    unsigned long long s = (unsigned long long)kPhaseDone << 32;
+    if (lane < 32u && f < bi.count) s = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t code = (uint32_t)(s >> 32), cnt = (uint32_t)s;
+    if (__ballot(code != kPhaseDone) == 0ull) break;
+    const bool is_s = code != kPhaseDone && (code & 3u) == kPhaseS, is_r = code != kPhaseDone && (code & 3u) == kPhaseRedo;
+    bool has = false;
+    if (is_s) {
+      const uint32_t t = __hip_atomic_load(&st->f[f].s_ticket[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      has = (t >> kPersistSlotBits) == (code >> 2) && (t & kPersistSlotMask) < cnt;
+    }
+    const uint64_t m = __ballot(has);
+    if (m != 0ull) {
+      const int sel = __ffsll((unsigned long long)m) - 1;  // the lowest frame with tiles left
+      const uint32_t frame = (uint32_t)sel;
+      uint32_t bounce = (uint32_t)__builtin_amdgcn_readlane((int)(code >> 2), sel);
+      uint32_t tiles = (uint32_t)__builtin_amdgcn_readlane((int)cnt, sel);
+      uint32_t old = 0u;
+      if (lane == 0u) old = __hip_atomic_fetch_add(&st->f[frame].s_ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+      if ((old >> kPersistSlotBits) != bounce) {  // the frame moved on meanwhile: the ticket is one of its current shade pass
+        const unsigned long long now = __hip_atomic_load(&st->state[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bounce = old >> kPersistSlotBits;
+        tiles = (uint32_t)now;
+        if ((uint32_t)(now >> 32) != ((bounce << 2) | kPhaseS)) {  // cannot be: a pass does not end before its tickets are out
+          if (lane == 0u) __hip_atomic_fetch_or(&st->error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      const uint32_t tile = old & kPersistSlotMask;
+      if (tile >= tiles) continue;  // another wavefront took the last one
+      spins = 0u;
+      // ---- one tile of (frame, bounce): k_shade_fused's arguments for this frame ----
+      const size_t fo = (size_t)frame * bi.stride;
+      DeviceCounters* ctr = counters + frame;
+      const uint32_t n_all = __hip_atomic_load(&ctr->live[bounce], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t* list = bounce == 0u ? pa.list0 : nullptr;
+      const uint32_t n = list ? __hip_atomic_load(&ctr->list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_all;
+      DPaths in = pa.paths[bounce & 1u], out = pa.paths[(bounce & 1u) ^ 1u];
+      in.o4 += fo;
+      in.d4 += fo;
+      in.t4 += fo;
+      out.o4 += fo;
+      out.d4 += fo;
+      out.t4 += fo;
+      DHits h = hits;
+      h.tp += fo;
+      h.nm += fo;
+      DFrame fb = pa.stage;
+      if (pa.staged) {
+        fb.color4 += fo;
+        fb.nd4 += fo;
+      }
+      const int last = (int)bounce == pa.max_bounces - 1 ? 1 : 0;
+      shade_tile<kSpheres, false, 1, true>(sc, pa.tail_begin, pa.tail_end, in, out, h, pa.staged, (int)bounce, last, pa.slot_base,
+                                           pa.tile_desc + (size_t)frame * pa.tile_stride, pa.epoch0 + bounce, fb, pa.band, ctr, nullptr, bi.iteration[frame],
+                                           list ? list + fo : nullptr, fo, tile, tiles, n, n_all, s_cnt, &s_excl);
+      // ---- sign the tile off; the last one opens the frame's next traversal phase ----
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // survivors, samples and the live count are in memory
+      uint32_t done = 0u;
+      if (lane == 0u) done = __hip_atomic_fetch_add(&st->f[frame].s_done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
+      if (done + 1u == tiles) {
+        const uint32_t next = bounce + 1u;
+        const uint32_t live = last ? 0u : __hip_atomic_load(&ctr->live[next], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (live == 0u) {
+          if (lane == 0u) {
+            __hip_atomic_store(&st->state[frame], (unsigned long long)kPhaseDone << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&st->frames_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          if (lane < 8u) __hip_atomic_store(&st->f[frame].cursor[lane][0], next << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 8u) __hip_atomic_store(&st->f[frame].t_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0u)
+            __hip_atomic_store(&st->state[frame], ((unsigned long long)((next << 2) | kPhaseT) << 32) | live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      continue;
+    }
+    const uint64_t mr = __ballot(is_r);
+    if (mr != 0ull) {
+      // the exact redo of the rays a frame's traversal phase set aside (rare: a handful per batch), one frame at a time
+      // (redo_slow_rays' stack is one per launch): claim the frame, take the lock, walk, publish, open the shade pass
+      const int sel = __ffsll((unsigned long long)mr) - 1;
+      const uint32_t frame = (uint32_t)sel;
+      const uint32_t rcode = (uint32_t)__builtin_amdgcn_readlane((int)code, sel), tiles = (uint32_t)__builtin_amdgcn_readlane((int)cnt, sel);
+      const uint32_t bounce = rcode >> 2;
+      unsigned long long expect = ((unsigned long long)rcode << 32) | tiles;
+      bool mine = false;
+      if (lane == 0u)
+        mine = __hip_atomic_compare_exchange_strong(&st->state[frame], &expect, ((unsigned long long)((bounce << 2) | kPhaseRedoing) << 32) | tiles,
+                                                    __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__ballot(mine) == 0ull) continue;
+      bool locked = false;
+      for (uint32_t w = 0u; w < (1u << 22) && !locked; ++w) {
+        uint32_t zero = 0u;
+        bool got = false;
+        if (lane == 0u) got = __hip_atomic_compare_exchange_strong(&st->redo_lock, &zero, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        locked = __ballot(got) != 0ull;
+        if (!locked) __builtin_amdgcn_s_sleep(20);
+      }
+      if (!locked) {
+        if (lane == 0u) {
+          __hip_atomic_fetch_or(&st->error, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicOr(&counters->flags, kFlagPersistStall);
+        }
+        break;
+      }
+      DeviceCounters* ctr = counters + frame;
+      const uint32_t count = __hip_atomic_load(&ctr->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      redo_slow_rays<true>(sc, obj_index, pa.paths[bounce & 1u], hits, pa.slow_list + (size_t)frame * bi.stride, count, counters);
+      // (its hit records are plain non-temporal stores: an agent-scope release writes them back before anybody is told)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0u) {
+        __hip_atomic_store(&ctr->slow_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&counters->slow_rays[bounce], (unsigned long long)count);
+        __hip_atomic_store(&st->redo_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0u)
+        __hip_atomic_store(&st->state[frame], ((unsigned long long)((bounce << 2) | kPhaseS) << 32) | tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      spins = 0u;
+      continue;
+    }
+    // nothing to do right now
+    __builtin_amdgcn_s_sleep(20);
+    ++spins;
+    if ((spins & 255u) == 255u && __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    if (spins > (1u << 22)) {
+      if (lane == 0u) {
+        __hip_atomic_fetch_or(&st->error, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(&counters->flags, kFlagPersistStall);
+      }
+      break;
+    }
+  }
+}
+
+template <bool kSpheres>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PT_T4_WAVES, PT_T4_WAVES)))
+void k_persist(DScene sc, uint32_t obj_index, DHits hits, DeviceCounters* counters, DBatchInfo bi, DPersistArgs pa)
+{
+  uint32_t arrival = 0u;
+  if (threadIdx.x == 0u) arrival = __hip_atomic_fetch_add(&pa.st->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  arrival = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrival);
+  if (arrival % pa.service_every == pa.service_every - 1u) {
+    persist_service<kSpheres>(sc, obj_index, pa, hits, counters, bi);
+  } else {
+    const DPaths unused{nullptr, nullptr, nullptr};
+    traverse4_walk<false, true, false, true>(sc, obj_index, unused, hits, 0, 0, counters, nullptr, nullptr, bi, false, &pa);
+  }
+}
+
+// The state of a batch's persistent launch, set up on the device (one wavefront, in stream order behind bounce 0's
+// traversal launch): every frame starts in S(0) with the tiles of what bounce 0's shade pass walks.
+__global__ __launch_bounds__(kWave) void k_persist_init(DPersist* st, DeviceCounters* counters, DBatchInfo bi, int listed0)
+{
+  const uint32_t f = threadIdx.x;
+  if (f == 0u) {
+    st->started = 0u;
+    st->frames_done = 0u;
+    st->redo_lock = 0u;
+    st->error = 0u;
+  }
+  if (f >= (uint32_t)kMaxBatch) return;
+  unsigned long long state = (unsigned long long)kPhaseDone << 32;
+  if (f < bi.count) {
+    DeviceCounters* ctr = counters + f;
+    const uint32_t n_all = ctr->live[0];
+    const uint32_t n = listed0 ? ctr->list_count : n_all;
+    const uint32_t tiles = (n + kServiceTile - 1u) / kServiceTile;
+    for (int r = 0; r < 8; ++r) st->f[f].cursor[r][0] = 0u;
+    st->f[f].t_done[0] = 0u;
+    st->f[f].s_ticket[0] = 0u;
+    st->f[f].s_done[0] = 0u;
+    ctr->slow_count = 0u;
+    if (tiles == 0u) {  // nothing alive (k_shade_fused's own case): nothing follows
+      ctr->live[1] = 0u;
+      ctr->rays_total += n_all;
+      ctr->paths[0] += n_all;
+    } else {
+      state = ((unsigned long long)((0u << 2) | kPhaseS) << 32) | tiles;
+    }
+  }
+  st->state[f] = state;
 }
 
 #include "pt_traverse4m.inc"
@@ -1137,6 +1572,15 @@ void launch_traverse(hipStream_t s, const DScene& scene, uint32_t obj_index, boo
     else hipLaunchKernelGGL((k_traverse4<false, false>), grid, block, 0, s, scene, obj_index, paths, hits, bounce, work_slot, counters, slow_list, order, bi, listed ? 1 : 0);
   }
 }
+void launch_persist(hipStream_t s, const DScene& scene, uint32_t obj_index, DHits hits, DeviceCounters* counters, const DBatchInfo& bi,
+                    const DPersistArgs& pa, uint32_t waves, bool spheres, bool listed0)
+{
+  hipLaunchKernelGGL(k_persist_init, dim3(1), dim3(kWave), 0, s, pa.st, counters, bi, listed0 ? 1 : 0);
+  const dim3 grid(waves), block(kWave);
+  if (spheres) hipLaunchKernelGGL((k_persist<true>), grid, block, 0, s, scene, obj_index, hits, counters, bi, pa);
+  else hipLaunchKernelGGL((k_persist<false>), grid, block, 0, s, scene, obj_index, hits, counters, bi, pa);
+}
+uint32_t persist_tiles_per_frame(uint32_t max_paths) { return div_up(max_paths, kServiceTile); }
 void launch_megakernel(hipStream_t s, const DScene& scene, const DCamera& cam, uint32_t iteration, DBand band,
                        uint32_t pix_count, int max_bounces, DFrame fb, DeviceCounters* counters)
 {

@@ -353,16 +353,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 // Slots per thread: 2 (round 4; 4 until then).  With four the kernel needs 128 registers and spills 18 of them at four
 // wavefronts per SIMD; with two it needs 88, spills nothing and runs five: config 2 +2.2 %, config 3 +0.6 ... 1.2 %;
 // one slot (eight wavefronts): -4 ... -6 % (profiles/r04_config2_counters.txt).  Six wavefronts (80 registers) spill 53.
-#ifndef PT_FUSE_K
-#define PT_FUSE_K 2
-#endif
-
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4
-#endif
-constexpr int kFuseK = PT_FUSE_K;
-constexpr uint32_t kFuseTile = 256u * kFuseK;
-static_assert(kFuseTile <= 256u * kListPer, "k_raygen / k_spheres scan their work lists on k_shade_fused's tile descriptors");
+#include "pt_shade_tile.inc"
 
 
 template <bool kSpheres, bool kFirst>
@@ -377,7 +368,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WA
   __shared__ uint32_t s_cnt[kFuseK * 4];
   const uint32_t frame = blockIdx.x % bi.count;  // frame-fastest: neighbouring blocks take their tickets on different lines
   const uint32_t iteration = bi.iteration[frame];
-  const uint32_t acc_iteration = staged ? 0u : iteration;
   const size_t fo = (size_t)frame * bi.stride;
   if (octs) octs += fo;
   in.o4 += fo;
@@ -401,7 +391,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WA
   const uint32_t n = list ? counters->list_count : n_all;
   if (list) list += fo;
   const uint32_t tiles = (n + kFuseTile - 1u) / kFuseTile;
-  const uint32_t wave = threadIdx.x >> 6;
   // The grid is sized for a frame of all-live slots; the workgroups the frame has no tile for leave without a ticket:
   // exactly `tiles` tickets are taken per frame.  (Dispatching the empty workgroups costs little: a launch sized by the
   // last batch's live counts, whose workgroups came back for more tiles when there were too few, was slower -- the
@@ -423,184 +412,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WA
   __syncthreads();
   const uint32_t tile = s_tile;
 
-  // ---- phase 1: rays and hits of the tile; the closest hit is final after the trailing sphere run ----
-  float4 o4[kFuseK], d4[kFuseK], tp[kFuseK], nm[kFuseK];
-  uint32_t have_nm = 0u, hit_mask = 0u;
-  uint32_t slot_of[kFuseK];  // position tile * kFuseTile + j * 256 + thread of the walk -> slot (the same unless `list`)
-#pragma unroll
-  for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t at = tile * kFuseTile + (uint32_t)j * 256u + threadIdx.x;
-    slot_of[j] = at < n ? (list ? list[at] - (uint32_t)fo : at) : n_all;
-  }
-#pragma unroll
-  for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = slot_of[j];
-    tp[j] = make_float4(-1.0f, 0.f, 0.f, 0.f);
-    nm[j] = o4[j] = d4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < n_all) {
-      o4[j] = ldnt(&in.o4[s]);
-      d4[j] = ldnt(&in.d4[s]);
-      if (!kFirst) tp[j] = ldnt(&hits.tp[s]);
-    }
-  }
-  // the sphere run that ends the object list: every lane with its own candidates, all its slots at once, when the run
-  // allows it (sphere_run_lanes); object by object otherwise
-  const bool lanes_run = kSpheres && PT_SPHERE_LANES && sc.lanes_run != 0u;
-  if (kSpheres && lanes_run) {
-    static_assert(kFuseK <= 4, "sphere_run_lanes: at most four slots");
-    uint32_t valid = 0u;
-#pragma unroll
-    for (int j = 0; j < kFuseK; ++j) valid |= slot_of[j] < n_all ? 1u << j : 0u;
-    have_nm |= sphere_run_lanes<kFuseK>(sc, obj_begin, obj_end, o4, d4, tp, nm, valid);
-  }
-#pragma unroll
-  for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = slot_of[j];
-    if (kSpheres && !lanes_run && s < n_all) {
-      Ray ray;
-      ray.o = xyz(o4[j]);
-      ray.d = xyz(d4[j]);
-      ray.tmin = (__float_as_uint(o4[j].w) >> 31) ? 1e-5f : 1e-4f;
-      ray.tmax = tp[j].x >= 0.0f ? tp[j].x : FLT_MAX;
-      Hit rec;
-      bool changed = false;
-      if (PT_FOLD_TAIL && sc.fold_run != 0u) sphere_fold(sc, obj_begin, obj_end, ray, rec, changed);
-      else sphere_segment(sc, obj_begin, obj_end, ray, rec, changed);
-      if (changed) {  // the record stays in registers: its only reader is this thread, a few lines down
-        tp[j] = make_float4(rec.t, rec.p.x, rec.p.y, rec.p.z);
-        nm[j] = make_float4(rec.n.x, rec.n.y, rec.n.z, __uint_as_float(rec.mat | (rec.side << 31)));
-        have_nm |= 1u << j;
-      }
-    }
-    const bool hit = s < n_all && tp[j].x >= 0.0f;
-    hit_mask |= hit ? 1u << j : 0u;
-    const uint64_t live = __ballot(hit && !last_bounce);
-    if ((threadIdx.x & 63u) == 0u) s_cnt[j * 4 + (int)wave] = (uint32_t)__popcll(live);
-  }
-  // what phase 2 still needs from memory, requested before anybody waits for anything
-  float4 t4[kFuseK];
-#pragma unroll
-  for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = slot_of[j];
-    t4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < n_all) t4[j] = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ldnt(&in.t4[s]);  // (k_raygen does not write it)
-    if (!kFirst && (hit_mask >> j & 1u) && !(have_nm >> j & 1u)) nm[j] = ldnt(&hits.nm[s]);
-  }
-  __syncthreads();
-  // ---- the tile's survivor count goes out (one round trip after the workgroup started) ----
-  uint32_t agg = 0u;
-#pragma unroll
-  for (int k = 0; k < kFuseK * 4; ++k) agg += s_cnt[k];
-  const unsigned long long tag = (unsigned long long)epoch << 34;
-  if (threadIdx.x == 0u)
-    __hip_atomic_store(&tile_desc[tile], tag | (tile == 0u ? kDescPrefix : kDescAggregate) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-  // ---- phase 2: material_kernel per slot, in place: the new ray and throughput of a survivor take the registers of the
-  // old ones (nothing is written yet: where to is known only after the look-back, which by then has had the whole of
-  // this phase to resolve); paths that end go into the framebuffer ----
-  uint32_t surv_mask = 0u;
-#pragma unroll
-  for (int j = 0; j < kFuseK; ++j) {
-    const uint32_t s = slot_of[j];
-    f3 ro = xyz(o4[j]), rd = xyz(d4[j]), color = xyz(t4[j]);
-    uint32_t pixbits = __float_as_uint(o4[j].w);
-    if (s < n_all) {
-      const uint32_t pixel = pixbits & 0x7fffffffu;
-      const uint32_t local_pixel = band_local(band, pixel);
-      bool tmin_flag = (pixbits >> 31) != 0u;
-#if PT_SHADE_KINDS
-      const bool is_hit = (hit_mask >> j & 1u) != 0u;
-      const f3 hn = xyz(nm[j]);
-      const uint32_t ms = __float_as_uint(nm[j].w);
-      DMaterial m{3, {0.f, 0.f, 0.f, 0.f}};  // (types are 0..2: validate_scene)
-      if (is_hit) m = sc.materials[ms & 0x7fffffffu];
-      if (bounce == 0) {
-        if (is_hit) accumulate_nd(fb.nd4, local_pixel, acc_iteration, hn, tp[j].x);  // path_tracer.cu:308-311
-        else accumulate_nd(fb.nd4, local_pixel, acc_iteration, -rd, 1e6f);           // raygen defaults, ray_gen.cu:26-28
-      }
-      const uint32_t slot = (slot_base ? *slot_base : 0u) + s;
-      shade_kinds((uint32_t)m.type, ro, rd, tmin_flag, mk3(tp[j].y, tp[j].z, tp[j].w), hn, ms >> 31, m, slot, iteration, (uint32_t)bounce, color);
-      if (!is_hit || last_bounce) {
-        // a miss ends the path with throughput * sky (path_tracer.cu:304-307, 283-289); capped paths deposit raw throughput
-        accumulate_color(fb.color4, local_pixel, acc_iteration, color);
-      } else {
-        surv_mask |= 1u << j;
-        o4[j] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixel | (tmin_flag ? 0x80000000u : 0u)));
-        d4[j] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-        t4[j] = make_float4(color.x, color.y, color.z, 0.0f);
-      }
-#else
-      if (!(hit_mask >> j & 1u)) {
-        // miss: throughput *= sky; the path ends (path_tracer.cu:304-307, 283-289)
-        color = color * background(rd);
-        if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, -rd, 1e6f);  // raygen defaults, ray_gen.cu:26-28
-        accumulate_color(fb.color4, local_pixel, acc_iteration, color);
-      } else {
-        const f3 hn = xyz(nm[j]);
-        if (bounce == 0) accumulate_nd(fb.nd4, local_pixel, acc_iteration, hn, tp[j].x);  // path_tracer.cu:308-311
-        const uint32_t ms = __float_as_uint(nm[j].w);
-        const DMaterial m = sc.materials[ms & 0x7fffffffu];
-        // RNG re-seeded from the global slot index, then discard(bounce) (path_tracer.cu:300-301)
-        const uint32_t slot = (slot_base ? *slot_base : 0u) + s;
-        Minstd rng;
-        rng.seed(path_seed(slot, iteration));
-        rng.discard((uint32_t)bounce);
-        const f3 hp = mk3(tp[j].y, tp[j].z, tp[j].w);
-        evaluate_material(ro, rd, tmin_flag, hp, hn, ms >> 31, m, rng, color);
-        if (last_bounce) {
-          accumulate_color(fb.color4, local_pixel, acc_iteration, color);  // capped paths deposit raw throughput
-        } else {
-          surv_mask |= 1u << j;
-          o4[j] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixel | (tmin_flag ? 0x80000000u : 0u)));
-          d4[j] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-          t4[j] = make_float4(color.x, color.y, color.z, 0.0f);
-        }
-      }
-#endif
-    }
-  }
-
-  // ---- the tile's offset comes in ----
-  if (wave == 0u) {
-    uint32_t excl = 0u;
-    if (tile != 0u) {
-      excl = tile_lookback(tile_desc, tile, epoch, &counters->flags);
-      if (threadIdx.x == 0u)
-        __hip_atomic_store(&tile_desc[tile], tag | kDescPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0u) {
-      s_excl = excl;
-      if (tile + 1u == tiles) {  // the last tile knows the frame's total (k_scan's epilogue)
-        counters->live[bounce + 1] = last_bounce ? 0u : excl + agg;
-        counters->rays_total += n_all;
-        counters->paths[bounce] += n_all;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- survivors to their stable place: tile offset + sub-blocks before + wavefronts before + lanes before ----
-  uint32_t base = s_excl;
-#pragma unroll
-  for (int j = 0; j < kFuseK; ++j) {
-    uint32_t before = 0u, in_sub = 0u;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t c = s_cnt[j * 4 + w];
-      before += (uint32_t)w < wave ? c : 0u;
-      in_sub += c;
-    }
-    const bool survives = (surv_mask >> j & 1u) != 0u;
-    const uint64_t live = __ballot(survives);
-    if (survives) {
-      const uint32_t dst = base + before + rank_below(live);
-      stnt(&out.o4[dst], o4[j]);
-      stnt(&out.d4[dst], d4[j]);
-      stnt(&out.t4[dst], t4[j]);
-      if (octs) octs[dst] = (uint8_t)((d4[j].x < 0.0f ? 1u : 0u) | (d4[j].y < 0.0f ? 2u : 0u) | (d4[j].z < 0.0f ? 4u : 0u));
-    }
-    base += in_sub;
-  }
+  // (the tile itself: pt_shade_tile.inc, shared with the persistent launch's service wavefronts)
+  shade_tile<kSpheres, kFirst, 4, false>(sc, obj_begin, obj_end, in, out, hits, staged, bounce, last_bounce, slot_base, tile_desc, epoch, fb, band, counters,
+                                         octs, iteration, list, fo, tile, tiles, n, n_all, s_cnt, &s_excl);
 }
 
 // Ray sorting ("ray_sort", BASELINE.json's ray-sorted wavefront; the reference keeps a sort_by_key by material

@@ -290,11 +290,16 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, (size_t)B * chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, (size_t)B * chunks)) return rc;
-    sl.tile_stride = shade_tiles_per_frame((uint32_t)P);
+    // (tile descriptors: k_shade_fused's 512-slot tiles, or the persistent launch's 128-slot ones)
+    sl.tile_stride = std::max(shade_tiles_per_frame((uint32_t)P), persist_tiles_per_frame((uint32_t)P));
     if (int rc = dev_alloc(ctx, pool, &sl.tile_desc, (size_t)B * sl.tile_stride)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(sl.tile_desc, 0, sizeof(unsigned long long) * (size_t)B * sl.tile_stride, ctx->stream));
     sl.shade_epoch = 0;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
+    if (B > 1) {
+      if (int rc = dev_alloc(ctx, pool, &sl.persist, 1)) return rc;
+      HIP_TRY(ctx, hipMemsetAsync(sl.persist, 0, sizeof(DPersist), ctx->stream));
+    }
     if (int rc = dev_alloc(ctx, pool, &sl.slow_stack, (size_t)kStackDepth * kWave)) return rc;
     if (ctx->beam) {
       ctx->beam_tiles_x = (width + kBeamTile - 1u) / kBeamTile;    // (ctx->width is set when everything has been allocated)
@@ -475,6 +480,24 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "beam must be 0 or 1");
     if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set beam before ptc_resize");
     ctx->beam = value != 0;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "persist") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "persist must be 0 or 1");
+    if (int rc = flush_pending(ctx)) return rc;
+    ctx->persist = value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "persist_service_every") == 0) {
+    if (value < 2 || value > 64) return fail(ctx, PTC_ERR_INVALID, "persist_service_every must be in [2, 64]");
+    if (int rc = flush_pending(ctx)) return rc;
+    ctx->persist_service_every = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "persist_min_frames") == 0) {
+    if (value < 1 || value > kMaxBatch) return fail(ctx, PTC_ERR_INVALID, "persist_min_frames must be in [1, 32]");
+    if (int rc = flush_pending(ctx)) return rc;
+    ctx->persist_min_frames = (uint32_t)value;
     return PTC_OK;
   }
   if (std::strcmp(name, "sphere_fold") == 0) {
@@ -666,6 +689,8 @@ int ptc_get_stats(ptc_ctx* ctx, ptc_stats* out)
   out->triangle_count = ctx->triangles;
   out->stack_capacity = kStackDepth;
   if (flags & kFlagStackOverflow) return fail(ctx, PTC_ERR_STACK, "traversal stack overflow during rendering");
+  if (flags & kFlagPersistStall)
+    return fail(ctx, PTC_ERR_HIP, "the persistent launch (k_persist) gave up waiting for work: a wavefront of its batch never finished (\"persist\" 0 turns it off)");
   if (flags & kFlagDispatchOrder)
     return fail(ctx, PTC_ERR_HIP, "k_shade_fused gave up waiting for a predecessor tile's survivor count: the image is invalid "
                                   "(set the parameter \"fused_shade\" to 0 to use the three-kernel path)");

@@ -74,6 +74,7 @@ struct ptc_ctx {
     uint32_t beam_count = 0;        // ... how many, for which scene upload and mesh object: the next batch of this slot with
     uint64_t beam_scene = 0;        //     the same cameras (a viewer that accumulates, the benchmark) skips k_beam
     uint32_t beam_obj = 0;
+    DPersist* persist = nullptr;    // "persist": the state of this slot's bounce-spanning launch (k_persist)
     uint32_t* slow_list = nullptr;  // slots of rays set aside for the exact redo at the end of a traversal launch
     uint32_t* slow_stack = nullptr; // that redo's traversal stack, [kStackDepth][kWave]
     uint8_t* octs = nullptr;        // "ray_sort": direction octant per slot of the rays of the next bounce
@@ -167,6 +168,11 @@ struct ptc_ctx {
   bool sphere_lanes = true;   // "sphere_lanes"
   bool sphere_fold = true;    // "sphere_fold"
   bool beam = true;           // "beam": primary rays start at their tile's entry points (k_beam)
+  // "persist": bounces >= 1 of a batch and every shade pass as ONE launch (k_persist) when the launch plan is
+  // one mesh object per bounce with nothing in front of it (ptcore_trace.cpp, persist_ok); 0: one launch per kernel and bounce
+  int persist = 1;
+  uint32_t persist_service_every = 5;  // "persist_service_every": one wavefront in this many shades, the others walk
+  uint32_t persist_min_frames = 2;     // "persist_min_frames": batches of fewer frames keep the per-bounce launches
   uint64_t scene_serial = 0;  // counts ptc_upload_scene calls (entry points computed for another scene are stale)
   uint32_t beam_tiles_x = 0, beam_tiles_y = 0;
   uint32_t traverse_waves = 5120;

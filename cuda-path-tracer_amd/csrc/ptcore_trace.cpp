@@ -261,6 +261,103 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
   return check_last(ctx, "bounce");
 }
 
+// May the batch that batch_begin has just opened run as bounce 0's traversal launch + ONE persistent launch (k_persist)?
+// The launch plan must be the simplest one -- every bounce is one traversal launch over one mesh object with nothing in front
+// of it, then the kernel that ends the bounce (a sphere run may end the object list) --, the shade pass the fused one, no ray
+// sorting, staged samples, no instrumentation (the counting runs and the per-launch events keep the per-bounce launches:
+// same results), and slots must fit the 26 bits a lane keeps them in.
+bool persist_ok(const ptc_ctx* ctx, int count)
+{
+  if (!ctx->persist || ctx->trace_variant != 3 || !ctx->fused_shade || ctx->ray_sort || !ctx->staging()) return false;
+  if (ctx->count_tests || ctx->max_bounces < 2 || count < (int)ctx->persist_min_frames) return false;
+  if (ctx->launches.size() != 1u || ctx->launches[0].pre_begin != ctx->launches[0].pre_end || launch_run(ctx, 0) != 1u) return false;
+  const auto& sl = ctx->slots[(size_t)ctx->active_slot];
+  if (!sl.persist || (uint64_t)sl.bi.stride * (uint64_t)count >= (1ull << kPersistSlotBits)) return false;
+  return true;
+}
+
+// The batch after raygen: bounce 0's traversal launch as ever (entry points, work list), then the persistent launch for
+// everything else -- every shade pass and the traversal of bounces 1 .. max_bounces - 1.
+int batch_persist(ptc_ctx* ctx, const uint32_t* slot_base_dev)
+{
+  auto& sl = ctx->slots[(size_t)ctx->active_slot];
+  const int MB = ctx->max_bounces;
+  DScene scene = ctx->scene;
+  scene.spill = sl.spill;
+  scene.slow_stack = sl.slow_stack;
+  const auto& l = ctx->launches[0];
+  scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];
+  // ---- bounce 0's closest hit: batch_bounce's traversal part ----
+  ptc_ctx::TimedLaunch tl{nullptr, nullptr, 0};
+  if (ctx->time_trace) {
+    for (hipEvent_t* e : {&tl.start, &tl.stop}) {
+      if (!ctx->free_events.empty()) {
+        *e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+      } else {
+        HIP_TRY(ctx, hipEventCreate(e));
+      }
+    }
+    HIP_TRY(ctx, hipEventRecord(tl.start, sl.stream));
+  }
+  const bool listed = sl.first_listed;
+  scene.beam = sl.beam;
+  launch_traverse(sl.stream, scene, l.mesh, true, sl.paths[0], sl.hits, 0, sl.work_slot++ % kWorkSlots, sl.counters, false,
+                  traverse_waves_for(ctx, sl.bi.count, 0, listed), sl.slow_list, listed ? sl.worklist : nullptr, 3, sl.bi, listed);
+  if (ctx->time_trace) {
+    HIP_TRY(ctx, hipEventRecord(tl.stop, sl.stream));
+    ctx->timed.push_back(tl);
+  }
+  // ---- everything else ----
+  scene.beam = DBeam{};
+  const bool tail = ctx->tail_begin < ctx->tail_end;
+  scene.lanes_run = tail ? lanes_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
+  scene.fold_run = tail && !scene.lanes_run ? fold_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
+  DPersistArgs pa{};
+  pa.st = sl.persist;
+  pa.paths[0] = sl.paths[0];
+  pa.paths[1] = sl.paths[1];
+  pa.max_bounces = MB;
+  pa.service_every = ctx->persist_service_every;
+  pa.tail_begin = tail ? ctx->tail_begin : 0u;
+  pa.tail_end = tail ? ctx->tail_end : 0u;
+  pa.staged = ctx->staging() ? 1 : 0;
+  pa.slot_base = slot_base_dev;
+  pa.tile_desc = sl.tile_desc;
+  pa.tile_stride = sl.tile_stride;
+  pa.epoch0 = next_epoch(sl);  // bounce b's pass: epoch0 + b
+  for (int b = 1; b < MB; ++b) next_epoch(sl);
+  if (sl.shade_epoch < pa.epoch0) {  // the epochs wrapped inside this batch: start the batch's run at 1 again
+    sl.shade_epoch = 0;
+    pa.epoch0 = next_epoch(sl);
+    for (int b = 1; b < MB; ++b) next_epoch(sl);
+  }
+  pa.stage = sl.stage;
+  pa.band = ctx->band;
+  pa.list0 = sl.primary_finished ? sl.worklist : nullptr;
+  pa.slow_list = sl.slow_list;
+  ptc_ctx::TimedLaunch tp{nullptr, nullptr, 1};
+  if (ctx->time_trace) {
+    for (hipEvent_t* e : {&tp.start, &tp.stop}) {
+      if (!ctx->free_events.empty()) {
+        *e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+      } else {
+        HIP_TRY(ctx, hipEventCreate(e));
+      }
+    }
+    HIP_TRY(ctx, hipEventRecord(tp.start, sl.stream));
+  }
+  launch_persist(sl.stream, scene, l.mesh, sl.hits, sl.counters, sl.bi, pa, ctx->traverse_waves, tail, pa.list0 != nullptr);
+  if (ctx->time_trace) {
+    HIP_TRY(ctx, hipEventRecord(tp.stop, sl.stream));
+    ctx->timed.push_back(tp);
+  }
+  sl.cur = MB & 1;
+  sl.bounces_done = MB;
+  return check_last(ctx, "persistent launch");
+}
+
 int batch_end(ptc_ctx* ctx)
 {
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
@@ -299,8 +396,16 @@ int flush_pending(ptc_ctx* ctx)
   std::vector<ptc_ctx::Pending> items;
   items.swap(ctx->pending);
   if (int rc = batch_begin(ctx, items.data(), (int)items.size())) return rc;
+  const uint32_t* slot_base = ctx->slot_offset ? ctx->slot_offset_dev : nullptr;
+  if (persist_ok(ctx, (int)items.size())) {
+    if (int rc = batch_persist(ctx, slot_base)) {
+      ctx->active_slot = -1;
+      return rc;
+    }
+    return batch_end(ctx);
+  }
   for (int b = 0; b < ctx->max_bounces; ++b)
-    if (int rc = batch_bounce(ctx, b, ctx->slot_offset ? ctx->slot_offset_dev : nullptr)) {
+    if (int rc = batch_bounce(ctx, b, slot_base)) {
       ctx->active_slot = -1;
       return rc;
     }
