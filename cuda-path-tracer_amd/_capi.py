@@ -93,7 +93,7 @@ class ptc_profile(C.Structure):
                 ("listed_rays", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
                 ("slow_rays", C.c_uint64 * PTC_MAX_BOUNCES_CAP),
                 ("node_visits", C.c_uint64 * PTC_MAX_BOUNCES_CAP), ("denoise_ms", C.c_double),
-                ("denoise_passes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("denoise_passes", C.c_uint32), ("persist_launches", C.c_uint32)]
 
 
 class ptc_upload_times(C.Structure):

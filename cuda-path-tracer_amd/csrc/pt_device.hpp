@@ -263,6 +263,7 @@ struct DPersist {
   uint32_t started, frames_done, redo_lock, error;
   uint32_t pad[28];
   DPersistFrame f[kMaxBatch];
+  uint32_t dbg[kMaxBatch][16][8];   // PT_PERSIST_DEBUG builds: per frame and bounce {n, rays fetched, rays finalized, tiles, tiles done, live out, .., ..}
 };
 struct DPersistArgs {
   DPersist* st;

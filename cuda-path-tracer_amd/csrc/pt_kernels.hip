@@ -259,14 +259,21 @@ struct PersistFeed {
         old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
         const uint32_t tag = old >> kPersistSlotBits, base = old & kPersistSlotMask;
         if (tag != cbounce) {  // the frame has moved on since this wavefront looked: the range is one of its current phase
-          const unsigned long long now = __hip_atomic_load(&st->state[cf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cbounce = tag;
-          set_geometry((uint32_t)now);
-          if ((uint32_t)(now >> 32) != ((tag << 2) | kPhaseT)) {  // cannot be: a T phase does not end before its rays are handed out
+          // (the phase's state word is stored BEFORE its cursors are re-tagged, so it is there; the wait is for a late store)
+          unsigned long long now = 0ull;
+          bool ok = false;
+          for (uint32_t w = 0u; w < (1u << 20) && !ok; ++w) {
+            now = __hip_atomic_load(&st->state[cf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (uint32_t)(now >> 32) == ((tag << 2) | kPhaseT);
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+          }
+          if (!ok) {  // cannot be: a T phase does not end before the rays it handed out are done
             if (threadIdx.x == 0u) __hip_atomic_fetch_or(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             have = false;
-            return -1;
+            return -2;
           }
+          cbounce = tag;
+          set_geometry((uint32_t)now);
         }
         if (base < clen) {
           begin = cf * stride + feed_rules::pos_of(crs, cr, base);
@@ -393,6 +400,9 @@ __device__ __forceinline__ void set_aside(DeviceCounters* counters, uint32_t* sl
 // sc1 forms of the hand-over stores and loads of the persistent launch (kPersist below): write-through / past the L1, so
 // that a wavefront on another XCD sees them (MI355X_MICROARCH.md, inter-workgroup visibility).  Hand-issued: the compiler
 // does not count them, which can only make one of its own waits longer; the loads carry their wait.
+// The store ends in s_nop 1: a store of more than 8 bytes reads its data registers for two more cycles, and the compiler, which
+// inserts that wait behind its own stores, does not look into a hand-written one (round 5's first build stored whatever the
+// next instruction had put into those registers: hit records with a pointer's bits in them).
 __device__ __forceinline__ void st_sc1(float4* p, const float4 v)
 {
   v4f w;
@@ -400,7 +410,7 @@ __device__ __forceinline__ void st_sc1(float4* p, const float4 v)
   w.y = v.y;
   w.z = v.z;
   w.w = v.w;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 __device__ __forceinline__ void ld2_sc1(const float4* pa, const float4* pb, float4& a, float4& b)
 {
@@ -567,12 +577,23 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     // (kPersist: one more ray of its frame is done -- counted here, added to the frame's counter by flush_done once the
     // stores above have landed)
     if (kPersist) __hip_atomic_fetch_add(&s_pend[slot >> kPersistSlotBits], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef PT_PERSIST_DEBUG
+    if (kPersist) {
+      const unsigned long long now = __hip_atomic_load(&pa->st->state[slot >> kPersistSlotBits], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(&pa->st->dbg[slot >> kPersistSlotBits][((uint32_t)(now >> 32) >> 2) & 15u][2], 1u);
+      if (((uint32_t)(now >> 32) & 3u) != kPhaseT) atomicAdd(&pa->st->dbg[slot >> kPersistSlotBits][15][7], 1u);  // finalized outside a T phase
+    }
+#endif
   };
   // kPersist: what this wavefront has finished since the last call goes onto the frames' counters; the lane whose add
   // completes a frame's traversal phase opens the phase behind it (the exact redo if rays were set aside, else the shade pass)
   auto flush_done = [&]() {
     if (!kPersist) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the hit records of what is counted are in memory (sc1 stores)
+#ifdef PT_PERSIST_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     uint32_t v = 0u;
     if (threadIdx.x < bi.count) v = s_pend[threadIdx.x];
     if (v != 0u) {
@@ -582,14 +603,23 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       const uint32_t old = __hip_atomic_fetch_add(&st->f[f].t_done[0], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long now = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t n = (uint32_t)now, b = (uint32_t)(now >> 32) >> 2;
+#ifdef PT_PERSIST_DEBUG
+      if (old + v > n) atomicAdd(&st->dbg[f][15][6], 1u);  // over-count
+#endif
       if (old + v == n) {
+#ifdef PT_PERSIST_DEBUG
+        st->dbg[f][b & 15u][0] = n;
+#endif
         const uint32_t slow = __hip_atomic_load(&counters[f].slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t tiles = (n + kServiceTile - 1u) / kServiceTile;
-        __hip_atomic_store(&st->f[f].s_ticket[0], b << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // order: the done counter, then the state word, then the ticket's tag -- a wavefront that draws a ticket of this pass
+        // (the tag says so) finds the state word there, and its sign-off cannot be wiped by the counter's reset
         __hip_atomic_store(&st->f[f].s_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&st->state[f], ((unsigned long long)((b << 2) | (slow ? kPhaseRedo : kPhaseS)) << 32) | tiles, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&st->f[f].s_ticket[0], b << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   };
@@ -882,7 +912,14 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       if (!active && mine < range_end) {
         float4 o4, d4;
         if (kPersist) {
+#ifdef PT_PERSIST_FENCES
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
           slot = mine | (cur_frame << kPersistSlotBits);
+#ifdef PT_PERSIST_DEBUG
+          atomicAdd(&pa->st->dbg[cur_frame][cur_bounce & 15u][1], 1u);
+#endif
           const DPaths& pin = pa->paths[cur_bounce & 1u];
           ld2_sc1(&pin.o4[mine], &pin.d4[mine], o4, d4);
         } else {
@@ -1074,6 +1111,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     if (got != 0) break;
     __builtin_amdgcn_s_sleep(20);
     if ((spins & 255u) == 255u && __hip_atomic_load(&pa->st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      if (threadIdx.x == 0u) atomicOr(&counters->flags, kFlagPersistStall);  // (somebody gave up: the host is told)
       got = -1;
       break;
     }
@@ -1086,7 +1124,10 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       break;
     }
   }
-  if (got < 0) break;
+  if (got < 0) {
+    if (got == -2 && threadIdx.x == 0u) atomicOr(&counters->flags, kFlagPersistStall);
+    break;
+  }
   dry = false;
   }
 #ifdef PT_TAILPROF
@@ -1261,18 +1302,31 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
       if (lane == 0u) old = __hip_atomic_fetch_add(&st->f[frame].s_ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
       if ((old >> kPersistSlotBits) != bounce) {  // the frame moved on meanwhile: the ticket is one of its current shade pass
-        const unsigned long long now = __hip_atomic_load(&st->state[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bounce = old >> kPersistSlotBits;
-        tiles = (uint32_t)now;
-        if ((uint32_t)(now >> 32) != ((bounce << 2) | kPhaseS)) {  // cannot be: a pass does not end before its tickets are out
-          if (lane == 0u) __hip_atomic_fetch_or(&st->error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long now = 0ull;
+        bool ok = false;
+        for (uint32_t w = 0u; w < (1u << 20) && !ok; ++w) {
+          now = __hip_atomic_load(&st->state[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (uint32_t)(now >> 32) == ((bounce << 2) | kPhaseS);
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) {  // cannot be: a pass does not end before the tiles it handed out are done
+          if (lane == 0u) {
+            __hip_atomic_fetch_or(&st->error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(&counters->flags, kFlagPersistStall);
+          }
           break;
         }
+        tiles = (uint32_t)now;
       }
       const uint32_t tile = old & kPersistSlotMask;
       if (tile >= tiles) continue;  // another wavefront took the last one
       spins = 0u;
       // ---- one tile of (frame, bounce): k_shade_fused's arguments for this frame ----
+#ifdef PT_PERSIST_FENCES
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       const size_t fo = (size_t)frame * bi.stride;
       DeviceCounters* ctr = counters + frame;
       const uint32_t n_all = __hip_atomic_load(&ctr->live[bounce], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1299,23 +1353,36 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
                                            list ? list + fo : nullptr, fo, tile, tiles, n, n_all, s_cnt, &s_excl);
       // ---- sign the tile off; the last one opens the frame's next traversal phase ----
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // survivors, samples and the live count are in memory
+#ifdef PT_PERSIST_FENCES
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       uint32_t done = 0u;
       if (lane == 0u) done = __hip_atomic_fetch_add(&st->f[frame].s_done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
       if (done + 1u == tiles) {
         const uint32_t next = bounce + 1u;
         const uint32_t live = last ? 0u : __hip_atomic_load(&ctr->live[next], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PT_PERSIST_DEBUG
+        if (lane == 0u) {
+          st->dbg[frame][bounce & 15u][3] = tiles;
+          st->dbg[frame][bounce & 15u][4] = n_all;
+          st->dbg[frame][bounce & 15u][5] = live;
+        }
+#endif
         if (live == 0u) {
           if (lane == 0u) {
             __hip_atomic_store(&st->state[frame], (unsigned long long)kPhaseDone << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&st->frames_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         } else {
-          if (lane < 8u) __hip_atomic_store(&st->f[frame].cursor[lane][0], next << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (lane == 8u) __hip_atomic_store(&st->f[frame].t_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // order: the done counter, then the state word, then the cursors' tags (see the hand-over to a shade pass)
+          if (lane == 0u) __hip_atomic_store(&st->f[frame].t_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0u)
             __hip_atomic_store(&st->state[frame], ((unsigned long long)((next << 2) | kPhaseT) << 32) | live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane < 8u) __hip_atomic_store(&st->f[frame].cursor[lane][0], next << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       continue;
@@ -1400,6 +1467,9 @@ void k_persist(DScene sc, uint32_t obj_index, DHits hits, DeviceCounters* counte
 __global__ __launch_bounds__(kWave) void k_persist_init(DPersist* st, DeviceCounters* counters, DBatchInfo bi, int listed0)
 {
   const uint32_t f = threadIdx.x;
+#ifdef PT_PERSIST_DEBUG
+  for (uint32_t i = f; i < (uint32_t)kMaxBatch * 16u * 8u; i += (uint32_t)kWave) (&st->dbg[0][0][0])[i] = 0u;
+#endif
   if (f == 0u) {
     st->started = 0u;
     st->frames_done = 0u;

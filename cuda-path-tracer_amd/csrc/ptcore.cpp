@@ -296,7 +296,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     HIP_TRY(ctx, hipMemsetAsync(sl.tile_desc, 0, sizeof(unsigned long long) * (size_t)B * sl.tile_stride, ctx->stream));
     sl.shade_epoch = 0;
     if (int rc = dev_alloc(ctx, pool, &sl.slow_list, BP)) return rc;
-    if (B > 1) {
+    if (ctx->staged) {
       if (int rc = dev_alloc(ctx, pool, &sl.persist, 1)) return rc;
       HIP_TRY(ctx, hipMemsetAsync(sl.persist, 0, sizeof(DPersist), ctx->stream));
     }
@@ -735,6 +735,7 @@ int ptc_reset_profile(ptc_ctx* ctx)
   std::memset(ctx->trace_launches, 0, sizeof ctx->trace_launches);
   ctx->denoise_ms = 0.0;
   ctx->denoise_passes = 0;
+  ctx->persist_launches = 0;
   ctx->intersect_redone = 0;
   const size_t off = offsetof(DeviceCounters, paths), end = offsetof(DeviceCounters, work);
   for (auto& sl : ctx->slots)
@@ -773,6 +774,7 @@ int ptc_get_profile(ptc_ctx* ctx, ptc_profile* out)
   out->slow_rays[0] += ctx->intersect_redone;
   out->denoise_ms = ctx->denoise_ms;
   out->denoise_passes = ctx->denoise_passes;
+  out->persist_launches = ctx->persist_launches;
   return PTC_OK;
 }
 

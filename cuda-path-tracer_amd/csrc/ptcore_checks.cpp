@@ -371,5 +371,15 @@ int ptc_selftest_math(ptc_ctx* ctx, const float* a, const float* b, uint32_t n, 
   return PTC_OK;
 }
 
+/* diagnostic (tools/debug): the persistent launch's state block of slot `slot`, after a synchronisation */
+int ptc_debug_persist(ptc_ctx* ctx, int slot, void* dst, uint64_t bytes)
+{
+  if (!ctx || !dst || slot < 0 || slot >= (int)ctx->slots.size() || !ctx->slots[(size_t)slot].persist) return PTC_ERR_INVALID;
+  if (int rc = bind_device(ctx)) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(dst, ctx->slots[(size_t)slot].persist, std::min<uint64_t>(bytes, sizeof(DPersist)), hipMemcpyDeviceToHost));
+  return PTC_OK;
+}
+
 }  // extern "C"
 

@@ -213,6 +213,7 @@ struct ptc_ctx {
   uint64_t intersect_redone = 0;         // rays ptc_intersect_rays redid exactly (reported as slow_rays[0])
   double denoise_ms = 0.0;               // A-Trous passes (TimedLaunch::bounce == -1)
   uint32_t denoise_passes = 0;
+  uint32_t persist_launches = 0;         // batches traced through k_persist since ptc_reset_profile
 };
 
 

@@ -355,6 +355,7 @@ int batch_persist(ptc_ctx* ctx, const uint32_t* slot_base_dev)
   }
   sl.cur = MB & 1;
   sl.bounces_done = MB;
+  ++ctx->persist_launches;
   return check_last(ctx, "persistent launch");
 }
 

@@ -283,7 +283,8 @@ class PathTracer:
                 "listed_rays": [int(x) for x in p.listed_rays[:n]],
                 "slow_rays": [int(x) for x in p.slow_rays[:n]],
                 "node_visits": [int(x) for x in p.node_visits[:n]],
-                "denoise_ms": float(p.denoise_ms), "denoise_passes": int(p.denoise_passes)}
+                "denoise_ms": float(p.denoise_ms), "denoise_passes": int(p.denoise_passes),
+                "persist_launches": int(p.persist_launches)}
 
     def intersect_rays(self, rays):
         """rays: [n, 8] float32 (origin, t_min, direction, t_max).  Returns t, normal, material, side."""

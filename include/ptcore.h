@@ -164,7 +164,7 @@ typedef struct ptc_profile {
   uint64_t node_visits[PTC_MAX_BOUNCES_CAP]; /* BVH node records fetched (counting runs): SURVEY 8(d)'s N_node */
   double denoise_ms;                         /* summed duration of the A-Trous passes (HIP events, while events are enabled) */
   uint32_t denoise_passes;
-  uint32_t reserved;
+  uint32_t persist_launches;                 /* batches whose bounces >= 1 and shade passes ran as ONE persistent launch ("persist", k_persist) */
 } ptc_profile;
 
 typedef struct ptc_ctx ptc_ctx;
@@ -440,6 +440,10 @@ int ptc_check_beam(const float* positions, uint32_t vertex_count, const uint32_t
                    const ptc_camera* camera, uint32_t width, uint32_t height, uint32_t stride, uint64_t* stats5, float* entries_out);
 /* Test hook: the same entries as k_beam computes them on the GPU for the uploaded scene's first traversal launch. */
 int ptc_debug_beam_entries(ptc_ctx* ctx, const ptc_camera* camera, float* entries_out, uint64_t capacity_floats);
+/* TEST / diagnostic: the state block (DPersist, pt_device.hpp) of slot `slot`'s persistent launch ("persist"), copied after a
+ * device synchronisation; its per-phase counters are filled in by -DPT_PERSIST_DEBUG builds only (tools/debug/persist_diff.py).
+ * No reference equivalent. */
+int ptc_debug_persist(ptc_ctx* ctx, int slot, void* dst, uint64_t bytes);
 
 /* Device self-test of the arithmetic contract the parity tests rely on: evaluates IEEE divide,
  * sqrt and the deterministic sin/cos on the GPU for n inputs (host arrays in, host arrays out). */
