@@ -251,10 +251,11 @@ struct DCameras {
 constexpr uint32_t kPersistSlotBits = 26u;  // a lane's ray: position in the batch (frame * stride + slot) | frame << 26
 constexpr uint32_t kPersistSlotMask = (1u << kPersistSlotBits) - 1u;
 constexpr uint32_t kPersistDyn = 128u;      // rays per cursor add (fixed: a cursor then only ever stands on multiples of it)
-constexpr uint32_t kPhaseT = 0u, kPhaseRedo = 1u, kPhaseRedoing = 2u, kPhaseS = 3u, kPhaseDone = 0xffffffffu;  // code = bounce << 2 | kind
+constexpr uint32_t kPhaseT = 0u, kPhaseRedo = 1u, kPhaseRedoing = 2u, kPhaseS = 3u, kPhaseDone = 0xffffffffu;  // code = bounce << 3 | kind
+constexpr uint32_t kPhaseKindBits = 3u, kPhaseKindMask = 7u;
 struct DPersistFrame {       // every hot word on a 128-byte line of its own
   uint32_t cursor[8][32];    // [region][0]: bounce << 26 | rays of the frame's current T phase handed out from that region
-  uint32_t t_done[32];       // [0]: rays of the current T phase whose results are in memory
+  uint32_t t_done[32];       // [0]: bounce << 26 | rays of the current T phase whose results are in memory
   uint32_t s_ticket[32];     // [0]: bounce << 26 | next tile of the current S phase
   uint32_t s_done[32];       // [0]: tiles of the current S phase finished
 };
@@ -270,6 +271,7 @@ struct DPersistArgs {
   DPaths paths[2];           // bounce b reads paths[b & 1] and writes paths[(b & 1) ^ 1]
   int max_bounces;
   uint32_t service_every;    // one wavefront in this many (by arrival) is a service wavefront
+  uint32_t help_tiles;       // tiles a walking wavefront shades when it finds no rays to hand out, before it looks for rays again
   uint32_t tail_begin, tail_end;  // the sphere run that ends the object list (k_shade_fused's obj_begin / obj_end)
   int staged;
   const uint32_t* slot_base;

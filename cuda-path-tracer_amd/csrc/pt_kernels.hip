@@ -229,43 +229,106 @@ struct BatchFeed {
 // (the add cannot be undone, and it need not be: the rays it stands for exist and nobody else will be given them).
 struct PersistFeed {
   DPersist* st;
+  DeviceCounters* ctr;
   uint32_t stride, count, home_r;
   bool have;                              // (cf, cr) below is a frame / region this wavefront last found rays in
-  uint32_t cf, cr, cbounce, cn, crs, clen;
-  __device__ __forceinline__ void init(DPersist* st_, const DBatchInfo& bi, uint32_t region)
+  uint32_t cf, cr, cbounce, cn, crs, clen, cdyn;
+  __device__ __forceinline__ void init(DPersist* st_, DeviceCounters* counters, const DBatchInfo& bi, uint32_t region)
   {
     st = st_;
+    ctr = counters;
     stride = bi.stride;
     count = bi.count;
     home_r = region & 7u;
     have = false;
     cf = cr = cbounce = cn = crs = clen = 0u;
   }
+  // Frame f = this lane (f < count): v more of its rays are done (their hit records in memory).  `old` is what the done
+  // counter held before this wavefront's add, `now` the frame's state word: the add that completes the phase's ray count
+  // opens the phase behind it -- the exact redo if rays were set aside, else the shade pass -- in the order done counter,
+  // state word, ticket tag (a wavefront that draws a ticket of the pass then finds the state word there, and its sign-off
+  // cannot be wiped by the counter's reset).
+  __device__ __forceinline__ void count_done(const uint32_t v, const uint32_t old, const unsigned long long now)
+  {
+    // (the counter carries its phase, bounce << 26, like the cursors: a count that belongs to a phase the state word no
+    // longer shows -- it was not the last one, and the frame has moved on while this wavefront's load was on its way --
+    // decides nothing)
+    const uint32_t f = threadIdx.x, n = (uint32_t)now, b = (uint32_t)(now >> 32) >> kPhaseKindBits;
+    if (v != 0u && (old >> kPersistSlotBits) == b && ((uint32_t)(now >> 32) & kPhaseKindMask) == kPhaseT && (old & kPersistSlotMask) + v == n) {
+      const uint32_t slow = __hip_atomic_load(&ctr[f].slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t tiles = (n + kServiceTile - 1u) / kServiceTile;
+#ifdef PT_PERSIST_DEBUG
+      st->dbg[f][b & 15u][0] = n;
+      st->dbg[f][b & 15u][2] = (uint32_t)wall_clock64();
+#endif
+      __hip_atomic_store(&st->f[f].s_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&st->state[f], ((unsigned long long)((b << kPhaseKindBits) | (slow ? kPhaseRedo : kPhaseS)) << 32) | tiles, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&st->f[f].s_ticket[0], b << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the same, on its own (two dependent round trips: only where the wavefront has nothing else to do)
+  __device__ __forceinline__ void flush(uint32_t& v)
+  {
+    if (v != 0u) {
+      const uint32_t old = __hip_atomic_fetch_add(&st->f[threadIdx.x].t_done[0], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long now = __hip_atomic_load(&st->state[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      count_done(v, old, now);
+    }
+    v = 0u;
+  }
   __device__ __forceinline__ void set_geometry(uint32_t n)
   {
     cn = n;
     crs = feed_rules::region_size_of(n);
     clen = feed_rules::region_len_of(n, crs, cr);
+    // rays per draw: all wavefronts of an XCD draw from ONE cursor (frames are dealt in order), and a cursor's line sustains
+    // ~30 adds per microsecond -- with 128 rays per draw the walk of a 770,000-ray phase spent more time queueing for its
+    // cursor than walking (measured: 2.3 x slower than the per-bounce launch, whose feed has 160 cursors and a static share)
+    cdyn = n >= 262144u ? 512u : (n >= 65536u ? 256u : kPersistDyn);
   }
-  // wave-uniform.  1: [begin, end) are batch positions (frame * stride + slot) of rays of `frame` entering `bounce`;
+  // batch position (frame * stride + slot) of the ray at region-local offset `local` of the range acquire handed out last
+  __device__ __forceinline__ uint32_t position_of(uint32_t local) const { return cf * stride + feed_rules::pos_of(crs, cr, local); }
+  // wave-uniform.  1: [begin, end) are REGION-LOCAL offsets (position_of) of rays of `frame` entering `bounce`;
   // 0: nothing to hand out right now (frames are between phases, or all rays of the running phases are out);
   // -1: every frame of the batch is done
-  __device__ __forceinline__ int acquire(uint32_t& begin, uint32_t& end, uint32_t& frame, uint32_t& bounce)
+  // v (lane f < count: finished rays of frame f not yet on its done counter, else 0) rides along: its adds are issued WITH
+  // the cursor's, so that a wavefront pays one round trip for both (the first build's separate flush in front of every
+  // refill -- a returning add, then a load of the state word -- made the walk 2.5 x slower); v comes back 0.
+  __device__ __forceinline__ int acquire(uint32_t& begin, uint32_t& end, uint32_t& frame, uint32_t& bounce, uint32_t& v)
   {
     for (int round = 0; round < 6; ++round) {
       if (have) {
-        uint32_t old = 0u;
-        if (threadIdx.x == 0u) old = __hip_atomic_fetch_add(&st->f[cf].cursor[cr][0], kPersistDyn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t old = 0u, dold = 0u;
+        unsigned long long dnow = 0ull;
+        const uint32_t drawn = cdyn;
+        if (threadIdx.x == 0u) old = __hip_atomic_fetch_add(&st->f[cf].cursor[cr][0], cdyn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0u) {
+          dold = __hip_atomic_fetch_add(&st->f[threadIdx.x].t_done[0], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dnow = __hip_atomic_load(&st->state[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        count_done(v, dold, dnow);
+        v = 0u;
         const uint32_t tag = old >> kPersistSlotBits, base = old & kPersistSlotMask;
         if (tag != cbounce) {  // the frame has moved on since this wavefront looked: the range is one of its current phase
           // (the phase's state word is stored BEFORE its cursors are re-tagged, so it is there; the wait is for a late store)
+          // (... unless the draw came after the phase's last ray was handed out: the frame may then be anywhere BEHIND T(tag),
+          // and the draw is simply a miss)
           unsigned long long now = 0ull;
-          bool ok = false;
-          for (uint32_t w = 0u; w < (1u << 20) && !ok; ++w) {
+          bool ok = false, past = false;
+          for (uint32_t w = 0u; w < (1u << 20) && !ok && !past; ++w) {
             now = __hip_atomic_load(&st->state[cf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = (uint32_t)(now >> 32) == ((tag << 2) | kPhaseT);
-            if (!ok) __builtin_amdgcn_s_sleep(2);
+            const uint32_t c = (uint32_t)(now >> 32);
+            ok = c == ((tag << kPhaseKindBits) | kPhaseT);
+            past = c == kPhaseDone || (c >> kPhaseKindBits) > tag || ((c >> kPhaseKindBits) == tag && (c & kPhaseKindMask) != kPhaseT);
+            if (!ok && !past) __builtin_amdgcn_s_sleep(2);
+          }
+          if (past) {
+            have = false;
+            continue;
           }
           if (!ok) {  // cannot be: a T phase does not end before the rays it handed out are done
             if (threadIdx.x == 0u) __hip_atomic_fetch_or(&st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -275,22 +338,23 @@ struct PersistFeed {
           cbounce = tag;
           set_geometry((uint32_t)now);
         }
-        if (base < clen) {
-          begin = cf * stride + feed_rules::pos_of(crs, cr, base);
-          end = begin + (min(clen, base + kPersistDyn) - base);
+        if (base < clen) {  // (region-local offsets: position_of maps a lane's own offset, so a draw may span blocks)
+          begin = base;
+          end = min(clen, base + drawn);
           frame = cf;
           bounce = cbounce;
           return 1;
         }
         have = false;
       }
+      flush(v);
       // every frame's state at once (lanes 0..31 and 32..63 both hold frame lane & 31: two regions are probed per step)
       const uint32_t f = threadIdx.x & 31u, half = threadIdx.x >> 5;
       unsigned long long s = (unsigned long long)kPhaseDone << 32;
       if (f < count) s = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t code = (uint32_t)(s >> 32), n = (uint32_t)s;
       if (__ballot(code != kPhaseDone) == 0ull) return -1;
-      const bool is_t = code != kPhaseDone && (code & 3u) == kPhaseT;
+      const bool is_t = code != kPhaseDone && (code & kPhaseKindMask) == kPhaseT;
       if (__ballot(is_t) == 0ull) return 0;
       const uint32_t rs = feed_rules::region_size_of(n);
       bool found = false;
@@ -300,7 +364,7 @@ struct PersistFeed {
         bool has = false;
         if (len != 0u) {
           const uint32_t c = __hip_atomic_load(&st->f[f].cursor[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          has = (c >> kPersistSlotBits) == (code >> 2) && (c & kPersistSlotMask) < len;
+          has = (c >> kPersistSlotBits) == (code >> kPhaseKindBits) && (c & kPersistSlotMask) < len;
         }
         const uint64_t m = __ballot(has);
         if (m != 0ull) {
@@ -310,7 +374,7 @@ struct PersistFeed {
           const int sel = flo <= fhi ? flo : fhi + 32;
           cf = (uint32_t)sel & 31u;
           cr = (home_r + dr + ((uint32_t)sel >> 5)) & 7u;
-          cbounce = (uint32_t)__builtin_amdgcn_readlane((int)(code >> 2), sel);
+          cbounce = (uint32_t)__builtin_amdgcn_readlane((int)(code >> kPhaseKindBits), sel);
           set_geometry((uint32_t)__builtin_amdgcn_readlane((int)n, sel));
           have = true;
           found = true;
@@ -432,7 +496,7 @@ __device__ __forceinline__ void ld2_sc1(const float4* pa, const float4* pb, floa
 // records are in memory), and when nothing can be handed out the wavefront finishes what it holds (the second loop),
 // waits, and starts over.  `paths` / `bounce` / `work_slot` / `order` / `listed` are unused then (pa->paths[bounce & 1]).
 template <bool kCount, bool kFirst, bool kBeam, bool kPersist = false>
-__device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
+__device__ __forceinline__ int traverse4_walk(const DScene& sc, uint32_t obj_index, const DPaths& paths, const DHits& hits,
                                                int bounce, int work_slot, DeviceCounters* counters, uint32_t* slow_list,
                                                const uint32_t* order, const DBatchInfo& bi, const bool listed,
                                                const DPersistArgs* pa = nullptr)
@@ -455,13 +519,13 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   uint32_t n_max = 0u;
   if (!kPersist) {
     for (uint32_t f = 0; f < bi.count; ++f) n_max = max(n_max, listed ? counters[f].list_count : counters[f].live[bounce]);
-    if (n_max == 0u) return;
+    if (n_max == 0u) return 0;
   }
   const DObject* obj = sc.objects + obj_index;
   const uint32_t mat = sc.object_material[obj_index];
   const float4* tris = sc.tris + kTriVec4 * (size_t)sc.object_tri_base[obj_index];
   // more wavefronts than batches (the margin keeps every wavefront that owns a static batch, see BatchFeed)
-  if (!kPersist && blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return;
+  if (!kPersist && blockIdx.x >= ((n_max + kWave - 1u) / kWave + 8u) * bi.count) return 0;
   // the object's world box: the same for every ray of the launch (scalar registers)
   auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
   const f3 obj_bmin = mk3(uni(obj->bmin[0]), uni(obj->bmin[1]), uni(obj->bmin[2]));
@@ -475,7 +539,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   BatchFeed feed;
   PersistFeed pfeed;
   if (kPersist) {
-    pfeed.init(pa->st, bi, blockIdx.x);
+    pfeed.init(pa->st, counters, bi, blockIdx.x);
     if (threadIdx.x < (uint32_t)kMaxBatch) s_pend[threadIdx.x] = 0u;
   } else {
     feed.init(counters, bi, bounce, work_slot, sc.static_eighths, listed);
@@ -483,6 +547,7 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
   uint32_t priv_next = 0u, priv_end = 0u;
   uint32_t cur_frame = 0u, cur_bounce = 0u;  // kPersist: whose rays [priv_next, priv_end) are
   bool dry = false;                           // kPersist: the feed had nothing to hand out when last asked
+  int walk_status = 0;                        // kPersist: what the feed said last: 0 nothing right now, < 0 every frame is done
 
   bool active = false;
   bool pending = false;
@@ -577,51 +642,20 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
     // (kPersist: one more ray of its frame is done -- counted here, added to the frame's counter by flush_done once the
     // stores above have landed)
     if (kPersist) __hip_atomic_fetch_add(&s_pend[slot >> kPersistSlotBits], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef PT_PERSIST_DEBUG
-    if (kPersist) {
-      const unsigned long long now = __hip_atomic_load(&pa->st->state[slot >> kPersistSlotBits], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicAdd(&pa->st->dbg[slot >> kPersistSlotBits][((uint32_t)(now >> 32) >> 2) & 15u][2], 1u);
-      if (((uint32_t)(now >> 32) & 3u) != kPhaseT) atomicAdd(&pa->st->dbg[slot >> kPersistSlotBits][15][7], 1u);  // finalized outside a T phase
-    }
-#endif
   };
   // kPersist: what this wavefront has finished since the last call goes onto the frames' counters; the lane whose add
   // completes a frame's traversal phase opens the phase behind it (the exact redo if rays were set aside, else the shade pass)
-  auto flush_done = [&]() {
-    if (!kPersist) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the hit records of what is counted are in memory (sc1 stores)
-#ifdef PT_PERSIST_FENCES
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+  // kPersist: finished rays per frame (lane f < count) whose hit records are in memory, taken off the wavefront's LDS counts
+  auto take_done = [&]() -> uint32_t {
     uint32_t v = 0u;
-    if (threadIdx.x < bi.count) v = s_pend[threadIdx.x];
-    if (v != 0u) {
-      const uint32_t f = threadIdx.x;
-      s_pend[f] = 0u;
-      DPersist* st = pa->st;
-      const uint32_t old = __hip_atomic_fetch_add(&st->f[f].t_done[0], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long now = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t n = (uint32_t)now, b = (uint32_t)(now >> 32) >> 2;
-#ifdef PT_PERSIST_DEBUG
-      if (old + v > n) atomicAdd(&st->dbg[f][15][6], 1u);  // over-count
-#endif
-      if (old + v == n) {
-#ifdef PT_PERSIST_DEBUG
-        st->dbg[f][b & 15u][0] = n;
-#endif
-        const uint32_t slow = __hip_atomic_load(&counters[f].slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t tiles = (n + kServiceTile - 1u) / kServiceTile;
-        // order: the done counter, then the state word, then the ticket's tag -- a wavefront that draws a ticket of this pass
-        // (the tag says so) finds the state word there, and its sign-off cannot be wiped by the counter's reset
-        __hip_atomic_store(&st->f[f].s_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&st->state[f], ((unsigned long long)((b << 2) | (slow ? kPhaseRedo : kPhaseS)) << 32) | tiles, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&st->f[f].s_ticket[0], b << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kPersist) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the hit records of what is counted are in memory (sc1 stores)
+      if (threadIdx.x < bi.count) {
+        v = s_pend[threadIdx.x];
+        if (v != 0u) __hip_atomic_fetch_sub(&s_pend[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+    return v;
   };
 
   // ---- work splitting: the tail of a launch -------------------------------------------------------------------
@@ -895,13 +929,16 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
 #endif
     if (!more) break;  // nothing left to fetch: the lanes still walking finish in the second loop
     if (more && (idle == (uint32_t)kWave || idle >= sc.refill_lanes)) {
-      flush_done();  // (what the previous refill finished: its stores have had a step's wait to land)
+      // (kPersist: when the feed has to be asked anyway, what earlier refills finished is reported with the same round trip;
+      // taken BEFORE this refill's finalize -- those stores have not landed yet)
+      uint32_t done_v = 0u;
+      if (kPersist && priv_next >= priv_end) done_v = take_done();
       if (pending) {
         finalize();  // (no ray is shared between lanes before the second loop)
         pending = false;
       }
       if (kPersist) {
-        if (priv_next >= priv_end && pfeed.acquire(priv_next, priv_end, cur_frame, cur_bounce) <= 0) {
+        if (priv_next >= priv_end && pfeed.acquire(priv_next, priv_end, cur_frame, cur_bounce, done_v) <= 0) {
           priv_next = priv_end = 0u;
           dry = true;
         }
@@ -912,16 +949,10 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
       if (!active && mine < range_end) {
         float4 o4, d4;
         if (kPersist) {
-#ifdef PT_PERSIST_FENCES
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-          slot = mine | (cur_frame << kPersistSlotBits);
-#ifdef PT_PERSIST_DEBUG
-          atomicAdd(&pa->st->dbg[cur_frame][cur_bounce & 15u][1], 1u);
-#endif
+          const uint32_t at = pfeed.position_of(mine);
+          slot = at | (cur_frame << kPersistSlotBits);
           const DPaths& pin = pa->paths[cur_bounce & 1u];
-          ld2_sc1(&pin.o4[mine], &pin.d4[mine], o4, d4);
+          ld2_sc1(&pin.o4[at], &pin.d4[at], o4, d4);
         } else {
           slot = order ? order[mine] : mine;  // (k_sort_octant: the same rays, picked up in a more coherent order)
           o4 = ldnt(&paths.o4[slot]);
@@ -1099,52 +1130,19 @@ __device__ __forceinline__ void traverse4_walk(const DScene& sc, uint32_t obj_in
 #endif
   }
   if (!kPersist) break;
-  // kPersist: this wavefront holds nothing any more.  Its counts go out, then it waits for rays: the feed is asked again
-  // every few hundred cycles (one load of the frames' state words when there is nothing), with a bound -- a wavefront that
-  // has waited about two seconds sets the launch's error word and leaves (everybody does, then: the host reports it).
+  // kPersist: this wavefront holds nothing any more.  Its counts go out; if there are rays to hand out it starts over, else
+  // it goes back to its caller (k_persist), which lets it shade tiles meanwhile and calls again.
   split_mode = false;
   since_split = since_retire = 0u;
-  flush_done();
-  int got = 0;
-  for (uint32_t spins = 0u;; ++spins) {
-    got = pfeed.acquire(priv_next, priv_end, cur_frame, cur_bounce);
-    if (got != 0) break;
-    __builtin_amdgcn_s_sleep(20);
-    if ((spins & 255u) == 255u && __hip_atomic_load(&pa->st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-      if (threadIdx.x == 0u) atomicOr(&counters->flags, kFlagPersistStall);  // (somebody gave up: the host is told)
-      got = -1;
-      break;
-    }
-    if (spins > (1u << 22)) {
-      if (threadIdx.x == 0u) {
-        __hip_atomic_fetch_or(&pa->st->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicOr(&counters->flags, kFlagPersistStall);
-      }
-      got = -1;
-      break;
-    }
-  }
-  if (got < 0) {
-    if (got == -2 && threadIdx.x == 0u) atomicOr(&counters->flags, kFlagPersistStall);
-    break;
-  }
+  uint32_t done_v = take_done();
+  pfeed.flush(done_v);
+  walk_status = pfeed.acquire(priv_next, priv_end, cur_frame, cur_bounce, done_v);
+  if (walk_status <= 0) break;
   dry = false;
   }
-#ifdef PT_TAILPROF
-  if (threadIdx.x == 0u && blockIdx.x < 8192u && bounce < 16) {
-    unsigned long long* tp = g_tailprof[bounce][blockIdx.x];
-    tp[0] = tp_start;
-    tp[1] = tp_exhausted;
-    tp[2] = wall_clock64();
-    tp[3] = ((unsigned long long)tp_iters << 40) | ((unsigned long long)tp_iters_exh << 16) | ((unsigned long long)tp_lanes_exh << 8) | min(tp_splits, 255u);
-    tp[4] = tp_c_retire;
-    tp[5] = tp_c_split;
-    tp[6] = tp_c_step;
-    tp[7] = tp_lanes_tail;
-  }
-#endif
   if (flags) atomicOr(&counters->flags, flags);
   if (kCount) flush_tally(tally, counters, bounce, false);
+  return walk_status;
 }
 
 // Rays a persistent traversal launch set aside (a direction with a zero / subnormal component, or a winner whose
@@ -1272,43 +1270,80 @@ void k_traverse4(DScene sc, uint32_t obj_index, DPaths paths, DHits hits, int bo
 // of its tile) only for tiles with lower tickets, which running wavefronts hold; T(f, b) needs S(f, b - 1), which needs
 // T(f, b - 1): a chain that starts at S(f, 0), ready when the launch starts.  Any five running wavefronts contain both
 // roles, so the launch ends however few of its wavefronts the chip admits at a time.  Every wait is bounded all the same.
+// Tiles a service wavefront draws with one ticket.  ONE: with four consecutive tiles per draw (measured, 7 x slower) the first
+// tile of a draw waits, in its look-back, for the LAST tile of the draw before it, which its wavefront has not even begun
+// while it works through the three in front -- the pass turns into a chain of draws.
+#ifndef PT_SERVICE_TILES
+#define PT_SERVICE_TILES 1u
+#endif
 template <bool kSpheres>
-__device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t obj_index, const DPersistArgs& pa, const DHits& hits,
-                                                DeviceCounters* counters, const DBatchInfo& bi)
+// dedicated: a service wavefront proper (stays until every frame is done, sleeps when there is nothing to shade); else a walking
+// wavefront that found no rays to hand out: it shades up to `budget` tiles and goes back to look for rays.  Returns < 0 when
+// every frame is done (or the launch has given up), else the tiles it shaded.
+__device__ __forceinline__ int persist_service(const DScene& sc, const uint32_t obj_index, const DPersistArgs& pa, const DHits& hits,
+                                               DeviceCounters* counters, const DBatchInfo& bi, const uint32_t arrival, const bool dedicated,
+                                               const uint32_t budget)
 {
+  uint32_t shaded = 0u;
   __shared__ uint32_t s_cnt[kFuseK];
   __shared__ uint32_t s_excl;
   DPersist* st = pa.st;
   const uint32_t lane = threadIdx.x, f = lane & 31u;
+  // Frames are SPREAD over the service wavefronts: each has a home frame and takes the first frame at or after it that has
+  // tiles left -- one ticket word sustains ~30 draws per microsecond, and with every wavefront on the lowest frame's word
+  // (the first build) a bounce-0 pass of 7200 tiles took 500 us however many wavefronts shaded (profiles/r05_persist_*.txt).
+  const uint32_t home = (dedicated ? arrival / pa.service_every : arrival) % bi.count;
+  bool have = false;       // (frame, bounce, tiles, n_all, n) below: the pass this wavefront last drew a ticket of
+  uint32_t frame = 0u, bounce = 0u, tiles = 0u, n_all = 0u, n = 0u;
   uint32_t spins = 0u;
   for (;;) {
-    unsigned long long s = (unsigned long long)kPhaseDone << 32;
-    if (lane < 32u && f < bi.count) s = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t code = (uint32_t)(s >> 32), cnt = (uint32_t)s;
-    if (__ballot(code != kPhaseDone) == 0ull) break;
-    const bool is_s = code != kPhaseDone && (code & 3u) == kPhaseS, is_r = code != kPhaseDone && (code & 3u) == kPhaseRedo;
-    bool has = false;
-    if (is_s) {
-      const uint32_t t = __hip_atomic_load(&st->f[f].s_ticket[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      has = (t >> kPersistSlotBits) == (code >> 2) && (t & kPersistSlotMask) < cnt;
+    uint32_t code = 0u, cnt = 0u;
+    bool is_r = false;
+    if (!have) {
+      unsigned long long s = (unsigned long long)kPhaseDone << 32;
+      if (lane < 32u && f < bi.count) s = __hip_atomic_load(&st->state[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      code = (uint32_t)(s >> 32);
+      cnt = (uint32_t)s;
+      if (__ballot(code != kPhaseDone) == 0ull) return -1;
+      const bool is_s = code != kPhaseDone && (code & kPhaseKindMask) == kPhaseS;
+      is_r = code != kPhaseDone && (code & kPhaseKindMask) == kPhaseRedo;
+      bool has = false;
+      if (is_s) {
+        const uint32_t t = __hip_atomic_load(&st->f[f].s_ticket[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        has = (t >> kPersistSlotBits) == (code >> kPhaseKindBits) && (t & kPersistSlotMask) < cnt;
+      }
+      const uint32_t m = (uint32_t)__ballot(has);  // (lanes 0..31)
+      if (m != 0u) {
+        const uint32_t at_or_after = m & ~((1u << home) - 1u);
+        const int sel = __ffs((int)(at_or_after ? at_or_after : m)) - 1;
+        frame = (uint32_t)sel;
+        bounce = (uint32_t)__builtin_amdgcn_readlane((int)(code >> kPhaseKindBits), sel);
+        tiles = (uint32_t)__builtin_amdgcn_readlane((int)cnt, sel);
+        n_all = __hip_atomic_load(&counters[frame].live[bounce], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n = (bounce == 0u && pa.list0) ? __hip_atomic_load(&counters[frame].list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_all;
+        have = true;
+      }
     }
-    const uint64_t m = __ballot(has);
-    if (m != 0ull) {
-      const int sel = __ffsll((unsigned long long)m) - 1;  // the lowest frame with tiles left
-      const uint32_t frame = (uint32_t)sel;
-      uint32_t bounce = (uint32_t)__builtin_amdgcn_readlane((int)(code >> 2), sel);
-      uint32_t tiles = (uint32_t)__builtin_amdgcn_readlane((int)cnt, sel);
+    if (have) {
       uint32_t old = 0u;
-      if (lane == 0u) old = __hip_atomic_fetch_add(&st->f[frame].s_ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0u) old = __hip_atomic_fetch_add(&st->f[frame].s_ticket[0], PT_SERVICE_TILES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
       if ((old >> kPersistSlotBits) != bounce) {  // the frame moved on meanwhile: the ticket is one of its current shade pass
         bounce = old >> kPersistSlotBits;
+        // (... unless the draw came after the pass's last tile was handed out: the frame may then be anywhere BEHIND S(bounce),
+        // and the draw is simply a miss.  Before S(bounce) -- the exact redo of the bounce -- the ticket is good: wait.)
         unsigned long long now = 0ull;
-        bool ok = false;
-        for (uint32_t w = 0u; w < (1u << 20) && !ok; ++w) {
+        bool ok = false, past = false;
+        for (uint32_t w = 0u; w < (1u << 20) && !ok && !past; ++w) {
           now = __hip_atomic_load(&st->state[frame], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (uint32_t)(now >> 32) == ((bounce << 2) | kPhaseS);
-          if (!ok) __builtin_amdgcn_s_sleep(2);
+          const uint32_t c = (uint32_t)(now >> 32);
+          ok = c == ((bounce << kPhaseKindBits) | kPhaseS);
+          past = c == kPhaseDone || (c >> kPhaseKindBits) > bounce;
+          if (!ok && !past) __builtin_amdgcn_s_sleep(2);
+        }
+        if (past) {
+          have = false;
+          continue;
         }
         if (!ok) {  // cannot be: a pass does not end before the tiles it handed out are done
           if (lane == 0u) {
@@ -1318,20 +1353,21 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
           break;
         }
         tiles = (uint32_t)now;
+        n_all = __hip_atomic_load(&counters[frame].live[bounce], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n = (bounce == 0u && pa.list0) ? __hip_atomic_load(&counters[frame].list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_all;
       }
-      const uint32_t tile = old & kPersistSlotMask;
-      if (tile >= tiles) continue;  // another wavefront took the last one
+      const uint32_t first = old & kPersistSlotMask;
+      if (first >= tiles) {  // the pass has no tiles left: look again
+        have = false;
+        continue;
+      }
       spins = 0u;
-      // ---- one tile of (frame, bounce): k_shade_fused's arguments for this frame ----
-#ifdef PT_PERSIST_FENCES
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      ++shaded;
+      const uint32_t end_tile = min(tiles, first + PT_SERVICE_TILES);
+      // ---- tiles [first, end_tile) of (frame, bounce): k_shade_fused's arguments for this frame ----
       const size_t fo = (size_t)frame * bi.stride;
       DeviceCounters* ctr = counters + frame;
-      const uint32_t n_all = __hip_atomic_load(&ctr->live[bounce], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t* list = bounce == 0u ? pa.list0 : nullptr;
-      const uint32_t n = list ? __hip_atomic_load(&ctr->list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_all;
       DPaths in = pa.paths[bounce & 1u], out = pa.paths[(bounce & 1u) ^ 1u];
       in.o4 += fo;
       in.d4 += fo;
@@ -1348,25 +1384,25 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
         fb.nd4 += fo;
       }
       const int last = (int)bounce == pa.max_bounces - 1 ? 1 : 0;
-      shade_tile<kSpheres, false, 1, true>(sc, pa.tail_begin, pa.tail_end, in, out, h, pa.staged, (int)bounce, last, pa.slot_base,
-                                           pa.tile_desc + (size_t)frame * pa.tile_stride, pa.epoch0 + bounce, fb, pa.band, ctr, nullptr, bi.iteration[frame],
-                                           list ? list + fo : nullptr, fo, tile, tiles, n, n_all, s_cnt, &s_excl);
-      // ---- sign the tile off; the last one opens the frame's next traversal phase ----
+#pragma unroll 1
+      for (uint32_t tile = first; tile < end_tile; ++tile)
+        shade_tile<kSpheres, false, 1, true>(sc, pa.tail_begin, pa.tail_end, in, out, h, pa.staged, (int)bounce, last, pa.slot_base,
+                                             pa.tile_desc + (size_t)frame * pa.tile_stride, pa.epoch0 + bounce, fb, pa.band, ctr, nullptr, bi.iteration[frame],
+                                             list ? list + fo : nullptr, fo, tile, tiles, n, n_all, s_cnt, &s_excl);
+      // ---- sign the tiles off; the last sign-off of a pass opens the frame's next traversal phase ----
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // survivors, samples and the live count are in memory
-#ifdef PT_PERSIST_FENCES
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      const uint32_t mine = end_tile - first;
       uint32_t done = 0u;
-      if (lane == 0u) done = __hip_atomic_fetch_add(&st->f[frame].s_done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0u) done = __hip_atomic_fetch_add(&st->f[frame].s_done[0], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
-      if (done + 1u == tiles) {
+      if (done + mine == tiles) {
+        have = false;
         const uint32_t next = bounce + 1u;
         const uint32_t live = last ? 0u : __hip_atomic_load(&ctr->live[next], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef PT_PERSIST_DEBUG
         if (lane == 0u) {
           st->dbg[frame][bounce & 15u][3] = tiles;
-          st->dbg[frame][bounce & 15u][4] = n_all;
+          st->dbg[frame][bounce & 15u][4] = (uint32_t)wall_clock64();   // S(bounce) complete = T(bounce + 1) opens
           st->dbg[frame][bounce & 15u][5] = live;
         }
 #endif
@@ -1377,14 +1413,15 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
           }
         } else {
           // order: the done counter, then the state word, then the cursors' tags (see the hand-over to a shade pass)
-          if (lane == 0u) __hip_atomic_store(&st->f[frame].t_done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0u) __hip_atomic_store(&st->f[frame].t_done[0], next << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0u)
-            __hip_atomic_store(&st->state[frame], ((unsigned long long)((next << 2) | kPhaseT) << 32) | live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->state[frame], ((unsigned long long)((next << kPhaseKindBits) | kPhaseT) << 32) | live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane < 8u) __hip_atomic_store(&st->f[frame].cursor[lane][0], next << kPersistSlotBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      if (!dedicated && shaded >= budget) return (int)shaded;
       continue;
     }
     const uint64_t mr = __ballot(is_r);
@@ -1392,13 +1429,13 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
       // the exact redo of the rays a frame's traversal phase set aside (rare: a handful per batch), one frame at a time
       // (redo_slow_rays' stack is one per launch): claim the frame, take the lock, walk, publish, open the shade pass
       const int sel = __ffsll((unsigned long long)mr) - 1;
-      const uint32_t frame = (uint32_t)sel;
-      const uint32_t rcode = (uint32_t)__builtin_amdgcn_readlane((int)code, sel), tiles = (uint32_t)__builtin_amdgcn_readlane((int)cnt, sel);
-      const uint32_t bounce = rcode >> 2;
-      unsigned long long expect = ((unsigned long long)rcode << 32) | tiles;
+      const uint32_t rframe = (uint32_t)sel;
+      const uint32_t rcode = (uint32_t)__builtin_amdgcn_readlane((int)code, sel), rtiles = (uint32_t)__builtin_amdgcn_readlane((int)cnt, sel);
+      const uint32_t rbounce = rcode >> kPhaseKindBits;
+      unsigned long long expect = ((unsigned long long)rcode << 32) | rtiles;
       bool mine = false;
       if (lane == 0u)
-        mine = __hip_atomic_compare_exchange_strong(&st->state[frame], &expect, ((unsigned long long)((bounce << 2) | kPhaseRedoing) << 32) | tiles,
+        mine = __hip_atomic_compare_exchange_strong(&st->state[rframe], &expect, ((unsigned long long)((rbounce << kPhaseKindBits) | kPhaseRedoing) << 32) | rtiles,
                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__ballot(mine) == 0ull) continue;
       bool locked = false;
@@ -1416,24 +1453,25 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
         }
         break;
       }
-      DeviceCounters* ctr = counters + frame;
+      DeviceCounters* ctr = counters + rframe;
       const uint32_t count = __hip_atomic_load(&ctr->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      redo_slow_rays<true>(sc, obj_index, pa.paths[bounce & 1u], hits, pa.slow_list + (size_t)frame * bi.stride, count, counters);
+      redo_slow_rays<true>(sc, obj_index, pa.paths[rbounce & 1u], hits, pa.slow_list + (size_t)rframe * bi.stride, count, counters);
       // (its hit records are plain non-temporal stores: an agent-scope release writes them back before anybody is told)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0u) {
         __hip_atomic_store(&ctr->slow_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(&counters->slow_rays[bounce], (unsigned long long)count);
+        atomicAdd(&counters->slow_rays[rbounce], (unsigned long long)count);
         __hip_atomic_store(&st->redo_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0u)
-        __hip_atomic_store(&st->state[frame], ((unsigned long long)((bounce << 2) | kPhaseS) << 32) | tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->state[rframe], ((unsigned long long)((rbounce << kPhaseKindBits) | kPhaseS) << 32) | rtiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       spins = 0u;
       continue;
     }
     // nothing to do right now
+    if (!dedicated) return (int)shaded;
     __builtin_amdgcn_s_sleep(20);
     ++spins;
     if ((spins & 255u) == 255u && __hip_atomic_load(&st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
@@ -1445,6 +1483,7 @@ __device__ __forceinline__ void persist_service(const DScene& sc, const uint32_t
       break;
     }
   }
+  return -1;  // (gave up: the launch's error word is set)
 }
 
 template <bool kSpheres>
@@ -1455,10 +1494,35 @@ void k_persist(DScene sc, uint32_t obj_index, DHits hits, DeviceCounters* counte
   if (threadIdx.x == 0u) arrival = __hip_atomic_fetch_add(&pa.st->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   arrival = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrival);
   if (arrival % pa.service_every == pa.service_every - 1u) {
-    persist_service<kSpheres>(sc, obj_index, pa, hits, counters, bi);
-  } else {
-    const DPaths unused{nullptr, nullptr, nullptr};
-    traverse4_walk<false, true, false, true>(sc, obj_index, unused, hits, 0, 0, counters, nullptr, nullptr, bi, false, &pa);
+    (void)persist_service<kSpheres>(sc, obj_index, pa, hits, counters, bi, arrival, true, 0u);
+    return;
+  }
+  // A walking wavefront: walk while there are rays to hand out; when there are none, shade a few tiles (the service
+  // wavefronts proper guarantee that the shade passes move while everybody walks -- these make them wide when the walk has
+  // nothing to do: at the launch's start, all of bounce 0's passes; later whatever keeps a frame from its next bounce);
+  // when there is neither, sleep.  Bounded like every wait of the launch.
+  const DPaths unused{nullptr, nullptr, nullptr};
+  for (uint32_t spins = 0u;;) {
+    const int walked = traverse4_walk<false, true, false, true>(sc, obj_index, unused, hits, 0, 0, counters, nullptr, nullptr, bi, false, &pa);
+    if (walked < 0) break;
+    const int shaded = pa.help_tiles ? persist_service<kSpheres>(sc, obj_index, pa, hits, counters, bi, arrival, false, pa.help_tiles) : 0;
+    if (shaded < 0) break;
+    if (shaded > 0) {
+      spins = 0u;
+      continue;
+    }
+    __builtin_amdgcn_s_sleep(20);
+    if ((++spins & 255u) == 255u && __hip_atomic_load(&pa.st->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      if (threadIdx.x == 0u) atomicOr(&counters->flags, kFlagPersistStall);  // (somebody gave up: the host is told)
+      break;
+    }
+    if (spins > (1u << 22)) {
+      if (threadIdx.x == 0u) {
+        __hip_atomic_fetch_or(&pa.st->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(&counters->flags, kFlagPersistStall);
+      }
+      break;
+    }
   }
 }
 
@@ -1469,6 +1533,9 @@ __global__ __launch_bounds__(kWave) void k_persist_init(DPersist* st, DeviceCoun
   const uint32_t f = threadIdx.x;
 #ifdef PT_PERSIST_DEBUG
   for (uint32_t i = f; i < (uint32_t)kMaxBatch * 16u * 8u; i += (uint32_t)kWave) (&st->dbg[0][0][0])[i] = 0u;
+#endif
+#ifdef PT_PERSIST_DEBUG
+  if (f == 0u) st->dbg[0][15][0] = (uint32_t)wall_clock64();
 #endif
   if (f == 0u) {
     st->started = 0u;
@@ -1493,7 +1560,7 @@ __global__ __launch_bounds__(kWave) void k_persist_init(DPersist* st, DeviceCoun
       ctr->rays_total += n_all;
       ctr->paths[0] += n_all;
     } else {
-      state = ((unsigned long long)((0u << 2) | kPhaseS) << 32) | tiles;
+      state = ((unsigned long long)((0u << kPhaseKindBits) | kPhaseS) << 32) | tiles;
     }
   }
   st->state[f] = state;

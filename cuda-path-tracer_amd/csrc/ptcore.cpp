@@ -494,6 +494,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->persist_service_every = (uint32_t)value;
     return PTC_OK;
   }
+  if (std::strcmp(name, "persist_help_tiles") == 0) {
+    if (value < 0 || value > 4096) return fail(ctx, PTC_ERR_INVALID, "persist_help_tiles must be in [0, 4096]");
+    if (int rc = flush_pending(ctx)) return rc;
+    ctx->persist_help_tiles = (uint32_t)value;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "persist_min_frames") == 0) {
     if (value < 1 || value > kMaxBatch) return fail(ctx, PTC_ERR_INVALID, "persist_min_frames must be in [1, 32]");
     if (int rc = flush_pending(ctx)) return rc;

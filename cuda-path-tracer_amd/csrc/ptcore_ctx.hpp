@@ -170,8 +170,9 @@ struct ptc_ctx {
   bool beam = true;           // "beam": primary rays start at their tile's entry points (k_beam)
   // "persist": bounces >= 1 of a batch and every shade pass as ONE launch (k_persist) when the launch plan is
   // one mesh object per bounce with nothing in front of it (ptcore_trace.cpp, persist_ok); 0: one launch per kernel and bounce
-  int persist = 1;
+  int persist = 0;  // (off: measured 3 x slower than the per-bounce launches, DESIGN section 4d -- the service wavefronts are latency-bound)
   uint32_t persist_service_every = 5;  // "persist_service_every": one wavefront in this many shades, the others walk
+  uint32_t persist_help_tiles = 8;     // "persist_help_tiles": tiles a walking wavefront without rays shades before it looks for rays again (0: it sleeps)
   uint32_t persist_min_frames = 2;     // "persist_min_frames": batches of fewer frames keep the per-bounce launches
   uint64_t scene_serial = 0;  // counts ptc_upload_scene calls (entry points computed for another scene are stale)
   uint32_t beam_tiles_x = 0, beam_tiles_y = 0;

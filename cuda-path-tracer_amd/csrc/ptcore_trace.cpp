@@ -319,6 +319,7 @@ int batch_persist(ptc_ctx* ctx, const uint32_t* slot_base_dev)
   pa.paths[1] = sl.paths[1];
   pa.max_bounces = MB;
   pa.service_every = ctx->persist_service_every;
+  pa.help_tiles = ctx->persist_help_tiles;
   pa.tail_begin = tail ? ctx->tail_begin : 0u;
   pa.tail_end = tail ? ctx->tail_end : 0u;
   pa.staged = ctx->staging() ? 1 : 0;

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _render(pkg, scene, flat, w, h, iters, mb, params=(), batch=None):
     with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+        pt.set_param("persist", 1)   # (not the default schedule: measured slower)
         for k, v in params:
             pt.set_param(k, v)
         if batch:

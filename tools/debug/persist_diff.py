@@ -19,6 +19,7 @@ flat = scene.build_scene()
 
 def render(params, batch):
     with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+        pt.set_param("persist", 1)
         for k, v in params:
             pt.set_param(k, v)
         pt.set_param("frames_in_flight", batch)
@@ -36,6 +37,7 @@ ref = render((("persist", 0),), iters)
 def render2(params, fif, batch):
     global iters
     with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+        pt.set_param("persist", 1)
         for k, v in params:
             pt.set_param(k, v)
         pt.set_param("frames_in_flight", fif)

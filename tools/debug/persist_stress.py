@@ -1,0 +1,50 @@
+"""Loop the persist test's configurations on the mesh-only scene; on an error dump the launch's state block."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import __graft_entry__ as g
+pkg = g.load_package()
+from cuda_path_tracer_amd import _capi
+w, h, iters, mb = 160, 96, 12, 6
+base = pkg.scenes.heightfield_scene((w, h), nx=65, nz=33)
+glm = pkg.glmlite
+s = pkg.SceneDescription()
+s.resolution, s.camera = (w, h), base.camera
+s.add_material("ground", pkg.DiffuseMateral((0.7, 0.7, 0.7)))
+mesh = list(base.mesh_map_.values())[0]
+s.add_mesh("ground", mesh)
+s.add_object(mesh, glm.translate((0.0, 0.0, 0.0)), "ground")
+flat = s.build_scene()
+cases = [((), (1, 12)), ((("persist_service_every", 2),), (1, 12)), ((("persist_service_every", 9), ("traverse_waves", 256)), (1, 12)),
+         ((("traverse_waves", 64),), (1, 6)), ((), (2, 3)), ((("beam", 0), ("filter_rays", 0)), (1, 4))]
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
+    for params, batch in cases:
+        pt = pkg.PathTracer(device=0, max_bounces=mb)
+        pt.set_param("persist", 1)
+        for k, v in params:
+            pt.set_param(k, v)
+        pt.set_param("frames_in_flight", batch[0] * batch[1])
+        pt.set_param("batch_frames", batch[1])
+        pt.create_buffers((w, h), flat)
+        pt.max_iterations = iters
+        for _ in range(iters):
+            pt.path_trace(s.camera)
+        try:
+            pt.stats()
+            print("ok", params, batch, flush=True)
+        except Exception as exc:
+            print("FAILED", params, batch, str(exc)[:80], flush=True)
+            size = 256 + 128 + 32 * 11 * 128 + 32 * 16 * 8 * 4
+            _capi.lib().ptc_debug_persist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+            for slot in range(batch[0]):
+                buf = (C.c_uint8 * size)()
+                if _capi.lib().ptc_debug_persist(pt._ctx, slot, buf, size):
+                    continue
+                raw = np.frombuffer(buf, dtype=np.uint32)
+                print("  slot", slot, "started/frames_done/lock/error", raw[64:68].tolist())
+                for f in range(batch[1]):
+                    code, cnt = int(raw[2 * f + 1]), int(raw[2 * f])
+                    fr = raw[96 + f * 352: 96 + (f + 1) * 352]
+                    print("   frame", f, "state code", hex(code), "(bounce", code >> 3, "kind", code & 7, ") count", cnt, "cursors", [hex(int(fr[r * 32])) for r in range(8)],
+                          "t_done", int(fr[256]), "s_ticket", hex(int(fr[288])), "s_done", int(fr[320]))
+        pt.close()
