@@ -158,6 +158,7 @@ SIGNATURES = {
     "ptc_check_beam": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_uint64), C.c_void_p]),
     "ptc_debug_beam_entries": (C.c_int, [_P, C.POINTER(ptc_camera), C.c_void_p, C.c_uint64]),
+    "ptc_debug_persist": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_uint64]),
     "ptc_check_feed": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "ptc_selftest_math": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -56,7 +56,6 @@ def render2(params, fif, batch):
         size = 256 + 128 + 32 * 11 * 128 + 32 * 16 * 8 * 4
         for slot in (0, 1):
             buf = (C.c_uint8 * size)()
-            _capi.lib().ptc_debug_persist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             rc = _capi.lib().ptc_debug_persist(pt._ctx, slot, buf, size)
             if rc: continue
             raw = np.frombuffer(buf, dtype=np.uint32)

@@ -35,7 +35,6 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
         except Exception as exc:
             print("FAILED", params, batch, str(exc)[:80], flush=True)
             size = 256 + 128 + 32 * 11 * 128 + 32 * 16 * 8 * 4
-            _capi.lib().ptc_debug_persist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
             for slot in range(batch[0]):
                 buf = (C.c_uint8 * size)()
                 if _capi.lib().ptc_debug_persist(pt._ctx, slot, buf, size):

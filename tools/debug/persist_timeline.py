@@ -26,7 +26,6 @@ with pkg.PathTracer(device=0, max_bounces=MB) as pt:
         pt.synchronize()
     size = 256 + 128 + 32 * 11 * 128 + 32 * 16 * 8 * 4
     buf = (C.c_uint8 * size)()
-    _capi.lib().ptc_debug_persist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     assert _capi.lib().ptc_debug_persist(pt._ctx, 0, buf, size) == 0
     raw = np.frombuffer(buf, dtype=np.uint32)
     dbg = raw[-32 * 16 * 8:].reshape(32, 16, 8).astype(np.int64)
