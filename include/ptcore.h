@@ -290,6 +290,13 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "static_eighths"   share of a launch's rays dealt to the wavefronts statically (default 4 = 4/8; 3 until round 4)
  *   "small_waves", "small_rays_per_lane"  a traversal launch with fewer than small_rays_per_lane (default 4) rays per lane of
  *                      "traverse_waves" wavefronts uses at most small_waves (default 3072) of them
+ *   "persist"          SCHEDULE (round 5; default 0): 1 = a batch of at least "persist_min_frames" (2) frames whose launch plan is one
+ *                      mesh object per bounce with nothing in front of it (fused shade, staged samples, no ray sorting, not instrumented)
+ *                      runs bounce 0's traversal as ever and then ONE launch for the traversal of bounces >= 1 and every shade pass
+ *                      (k_persist: one wavefront in "persist_service_every" (5) shades tiles, the others walk; a walking wavefront
+ *                      without rays shades "persist_help_tiles" (8) tiles before it looks again).  Bit-identical (tests/test_gpu_persist.py),
+ *                      measured 0.58 x the per-bounce launches: off.  Its waits are bounded: a launch that gives up
+ *                      makes ptc_get_stats fail with PTC_ERR_HIP instead of hanging.  Any time (queued frames are flushed first)
  *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small
  *                      scenes exercise the global overflow area (1..24; before ptc_upload_scene)
  *   "debug_force_slow" test hook: route every ray through the exact redo at the end of the traversal launch */
