@@ -96,6 +96,7 @@ void free_slots(ptc_ctx* ctx)
   }
   ctx->slots.clear();
   ctx->pending.clear();
+  ctx->held.clear();
   ctx->active_slot = -1;
   ctx->est_valid = false;
 }
@@ -194,6 +195,8 @@ void ptc_destroy(ptc_ctx* ctx)
     (void)hipEventDestroy(tl.stop);
   }
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->turn_event)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
   if (ctx->main_event) (void)hipEventDestroy(ctx->main_event);
   if (ctx->xstream_event) (void)hipEventDestroy(ctx->xstream_event);
@@ -352,7 +355,7 @@ int ptc_restart(ptc_ctx* ctx)
   // Iterations still queued are traced first, not dropped: the reference has rendered them by the time restart()
   // runs (path_trace is synchronous there), and a present between restart and the next path_trace shows them.
   // A viewer restarts after it has presented, i.e. with an empty queue, so this costs nothing where it matters.
-  if (!ctx->pending.empty())
+  if (!ctx->pending.empty() || !ctx->held.empty())
     if (int rc = flush_pending(ctx)) return rc;
   ctx->iteration = 0;
   return PTC_OK;
@@ -492,6 +495,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value < 2 || value > 64) return fail(ctx, PTC_ERR_INVALID, "persist_service_every must be in [2, 64]");
     if (int rc = flush_pending(ctx)) return rc;
     ctx->persist_service_every = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "pair_batches") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "pair_batches must be 0 or 1");
+    if (int rc = flush_pending(ctx)) return rc;
+    ctx->pair_batches = value;
     return PTC_OK;
   }
   if (std::strcmp(name, "persist_help_tiles") == 0) {

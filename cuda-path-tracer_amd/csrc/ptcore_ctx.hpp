@@ -108,6 +108,15 @@ struct ptc_ctx {
     uint32_t iteration;
   };
   std::vector<Pending> pending;
+  // "pair_batches" (round 5, measured: see DESIGN section 4d, the alternative that needs no hand-over inside a launch): a full
+  // batch is HELD until the next one is full (or anything else looks at the context); the two are then enqueued bounce by
+  // bounce on their two slots, and events make their traversal launches take turns -- A.T(0), B.T(0), A.T(1), ... -- so that the
+  // kernels that end a bounce of one batch run beside the traversal launch of the other instead of beside nothing
+  std::vector<Pending> held;
+  int pair_batches = 0;
+  hipEvent_t turn_event[2] = {nullptr, nullptr};  // recorded behind the traversal launches of a pair's two batches
+  int turn_wait = -1;                             // which of them the next traversal launch of the pair waits for (-1: none)
+  int turn_mine = -1;                             // which one the batch being enqueued records (-1: not a pair)
   uint64_t batches_issued = 0;
   // Slots [0, big_slots) hold `batch` frames each; slots [big_slots, slots.size()) hold ONE frame: a batch of a
   // single iteration (a viewer that presents after every iteration, the stepwise calls) goes to one of those, so
@@ -236,7 +245,7 @@ int check_last(ptc_ctx* ctx, const char* what);
 int bind_device(ptc_ctx* ctx);
 void free_pool(std::vector<void*>& pool);
 DCamera make_camera(const ptc_camera& c, uint32_t w, uint32_t h);
-int flush_pending(ptc_ctx* ctx);  // enqueue the iterations ptc_trace has queued (ptcore_trace.cpp)
+int flush_pending(ptc_ctx* ctx, bool from_trace = false);  // enqueue the iterations ptc_trace has queued (ptcore_trace.cpp)
 int sync_frames(ptc_ctx* ctx);
 void free_slots(ptc_ctx* ctx);
 int frame_ready(ptc_ctx* ctx);

@@ -213,6 +213,8 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
                        sl.tile_desc, sl.tile_stride, by_spheres ? next_epoch(sl) : 0u);
         wrote = true;
       }
+      // ("pair_batches": this batch's traversal launches wait for the partner's previous one, and say when they are done)
+      if (ctx->turn_mine >= 0 && ctx->turn_wait >= 0) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->turn_event[ctx->turn_wait], 0));
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
       if (int rc = timed_begin(tl)) return rc;
       const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce, listed);
@@ -230,6 +232,10 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       }
       wrote = true;
       if (int rc = timed_end(tl)) return rc;
+      if (ctx->turn_mine >= 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->turn_event[ctx->turn_mine], sl.stream));
+        ctx->turn_wait = ctx->turn_mine;
+      }
     }
   } else {
     ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
@@ -390,13 +396,9 @@ int batch_limit(const ptc_ctx* ctx) { return ctx->staged && ctx->trace_variant =
 }  // namespace
 
 namespace ptcd {
-// enqueue the iterations ptc_trace has queued
-int flush_pending(ptc_ctx* ctx)
+// one whole batch on the next slot: raygen, the bounces (per-bounce launches or the persistent launch), the fold
+static int enqueue_batch(ptc_ctx* ctx, std::vector<ptc_ctx::Pending>& items)
 {
-  if (ctx->pending.empty()) return PTC_OK;
-  if (int rc = bind_device(ctx)) return rc;
-  std::vector<ptc_ctx::Pending> items;
-  items.swap(ctx->pending);
   if (int rc = batch_begin(ctx, items.data(), (int)items.size())) return rc;
   const uint32_t* slot_base = ctx->slot_offset ? ctx->slot_offset_dev : nullptr;
   if (persist_ok(ctx, (int)items.size())) {
@@ -413,6 +415,60 @@ int flush_pending(ptc_ctx* ctx)
     }
   return batch_end(ctx);
 }
+
+// two batches bounce by bounce on two slots, their traversal launches taking turns ("pair_batches")
+static int enqueue_pair(ptc_ctx* ctx, std::vector<ptc_ctx::Pending>& a, std::vector<ptc_ctx::Pending>& b)
+{
+  for (hipEvent_t& e : ctx->turn_event)
+    if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const uint32_t* slot_base = ctx->slot_offset ? ctx->slot_offset_dev : nullptr;
+  if (int rc = batch_begin(ctx, a.data(), (int)a.size())) return rc;
+  const int slot_a = ctx->active_slot;
+  if (int rc = batch_begin(ctx, b.data(), (int)b.size())) return rc;
+  const int slot_b = ctx->active_slot;
+  ctx->turn_wait = -1;
+  int rc = PTC_OK;
+  for (int bounce = 0; bounce < ctx->max_bounces && rc == PTC_OK; ++bounce) {
+    ctx->active_slot = slot_a;
+    ctx->turn_mine = 0;
+    rc = batch_bounce(ctx, bounce, slot_base);
+    if (rc != PTC_OK) break;
+    ctx->active_slot = slot_b;
+    ctx->turn_mine = 1;
+    rc = batch_bounce(ctx, bounce, slot_base);
+  }
+  ctx->turn_mine = ctx->turn_wait = -1;
+  if (rc != PTC_OK) {
+    ctx->active_slot = -1;
+    return rc;
+  }
+  ctx->active_slot = slot_a;
+  if (int rc2 = batch_end(ctx)) return rc2;
+  ctx->active_slot = slot_b;
+  return batch_end(ctx);
+}
+
+// enqueue the iterations ptc_trace has queued
+int flush_pending(ptc_ctx* ctx, bool from_trace)
+{
+  if (ctx->pending.empty() && ctx->held.empty()) return PTC_OK;
+  if (int rc = bind_device(ctx)) return rc;
+  // "pair_batches": a batch that ptc_trace has just filled waits for its partner
+  const bool pairing = ctx->pair_batches && ctx->big_slots >= 2 && ctx->staging() && ctx->trace_variant == 3 && !ctx->persist;
+  if (pairing && from_trace && ctx->held.empty() && (int)ctx->pending.size() >= batch_limit(ctx) && batch_limit(ctx) > 1) {
+    ctx->held.swap(ctx->pending);
+    return PTC_OK;
+  }
+  std::vector<ptc_ctx::Pending> first, second;
+  first.swap(ctx->held);
+  second.swap(ctx->pending);
+  if (first.empty()) first.swap(second);
+  if (!second.empty() && pairing && first.size() > 1 && second.size() > 1) return enqueue_pair(ctx, first, second);
+  if (int rc = enqueue_batch(ctx, first)) return rc;
+  if (!second.empty()) return enqueue_batch(ctx, second);
+  return PTC_OK;
+}
+
 }  // namespace ptcd
 
 extern "C" {
@@ -530,7 +586,7 @@ int ptc_trace(ptc_ctx* ctx, const ptc_camera* camera)
   ++ctx->iteration;
   ++ctx->frames;
   ctx->result = ctx->fb.color4;  // path_tracer.cu:476
-  if ((int)ctx->pending.size() >= batch_limit(ctx)) return flush_pending(ctx);
+  if ((int)ctx->pending.size() >= batch_limit(ctx)) return flush_pending(ctx, true);
   return PTC_OK;
 }
 

@@ -297,6 +297,9 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      without rays shades "persist_help_tiles" (8) tiles before it looks again).  Bit-identical (tests/test_gpu_persist.py),
  *                      measured 0.58 x the per-bounce launches: off.  Its waits are bounded: a launch that gives up
  *                      makes ptc_get_stats fail with PTC_ERR_HIP instead of hanging.  Any time (queued frames are flushed first)
+ *   "pair_batches"     SCHEDULE (round 5; default 0): 1 = a full batch is held until the next one is full (or anything else looks at
+ *                      the context); the two are enqueued bounce by bounce on two slots and their traversal launches take turns.
+ *                      Bit-identical, measured 6-7 % slower than the default (profiles/r05_pair_batches.txt): off.  Any time
  *   "debug_lds_entries" test hook: keep only this many of the 24 per-lane traversal stack entries in LDS, so that small
  *                      scenes exercise the global overflow area (1..24; before ptc_upload_scene)
  *   "debug_force_slow" test hook: route every ray through the exact redo at the end of the traversal launch */

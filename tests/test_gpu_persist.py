@@ -91,3 +91,28 @@ def test_persistent_launch_at_benchmark_size(pkg, orc):
     got = _render(pkg, scene, flat, w, h, iters, mb, batch=(1, 6))
     assert got["persist_launches"] >= 1
     _same(got, ref, "1080p")
+
+
+def test_paired_batches_take_turns(pkg, orc):
+    """ "pair_batches": a full batch is held until the next one is full, the two are enqueued bounce by bounce on two slots and
+    events make their traversal launches alternate.  A schedule: same bits; a lone batch (the last, odd one) goes out alone, and
+    anything that looks at the context flushes what is held."""
+    w, h, mb = 128, 80, 5
+    scene = pkg.scenes.heightfield_scene((w, h), nx=33, nz=17)
+    flat = scene.build_scene()
+    for iters, batch in ((12, 3), (9, 3), (7, 2)):
+        ref = orc.render_streaming(flat, scene.camera, w, h, 0, iters, mb)
+        with pkg.PathTracer(device=0, max_bounces=mb) as pt:
+            pt.set_param("pair_batches", 1)
+            pt.set_param("frames_in_flight", 2 * batch)
+            pt.set_param("batch_frames", batch)
+            pt.create_buffers((w, h), flat)
+            pt.max_iterations = iters
+            for k in range(iters):
+                pt.path_trace(scene.camera)
+                if k == 4:
+                    assert pt.iteration() == 5      # (held or queued iterations count as rendered, as in the reference)
+            got = {k: pt.download(k) for k in ("color", "normal", "depth")}
+            st = pt.stats()
+            got["rays"], got["live"], got["persist_launches"] = st["rays_total"], st["last_live"], 0
+        _same(got, ref, ("pair_batches", iters, batch))
