@@ -241,6 +241,20 @@ struct DCameras {
   DCamera c[kMaxBatch];
 };
 
+// "prefold" (round 5, review item 4): the kernel that ends bounce b has a survivor's NEXT ray in registers; when the next bounce
+// opens with a sphere run in front of a mesh (a room's walls: config 2) it tests that run there and then -- the hit record of
+// bounce b + 1 goes straight to the survivor's new slot (a second set of hit records: other tiles still read this bounce's),
+// one byte says whether the ray may reach the mesh launch's boxes -- and bounce b + 1 starts with k_list_flags (the work list
+// from those bytes) instead of k_spheres' pass over every ray.
+struct DNextRun {
+  uint32_t begin, end;            // the sphere run in front of the next bounce's first traversal launch (objects)
+  uint32_t filt_begin, filt_end;  // the mesh objects of that launch (may_hit_boxes)
+  uint32_t fold_run;              // the run may take sphere_fold (every object a translated sphere)
+  uint32_t pad;
+  DHits hits;                     // the NEXT bounce's hit records
+  uint8_t* flags;                 // per new slot: 1 = the ray goes on the traversal launch's work list
+};
+
 // ---- the bounce-spanning persistent launch (k_persist, round 5) ------------------------------------
 // One launch per batch carries the traversal of bounces >= 1 and the shade passes of ALL bounces: of every five wavefronts
 // four walk rays (traverse4_walk<.., kPersist>) and one shades tiles (shade_tile<.., 1, true>).  Frame f moves through
@@ -377,7 +391,16 @@ void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHi
 void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths in, DPaths out,
                         DHits hits, uint32_t max_paths, bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
                         unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb, DBand band,
-                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list = nullptr);
+                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list = nullptr,
+                        const DNextRun* next = nullptr);
+// "prefold" at bounce 0: ray generation that also walks the sphere run in front of bounce 0's first mesh launch (next.hits: the
+// CURRENT bounce's records here) and leaves the bytes for launch_list_flags
+void launch_raygen_next(hipStream_t s, const DScene& scene, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count, DPaths paths,
+                        DeviceCounters* counters, const DNextRun& next);
+// "prefold": the work list of a bounce whose leading sphere run the previous bounce's shade kernel has already walked, from the
+// bytes it left (k_list_flags; tile_desc / epoch as for launch_spheres)
+void launch_list_flags(hipStream_t s, const uint8_t* flags, uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi,
+                       uint32_t* worklist, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch);
 uint32_t shade_tiles_per_frame(uint32_t max_paths);
 void launch_accumulate(hipStream_t s, DFrame stage, DFrame fb, uint32_t pix_count, const DBatchInfo& bi);
 // the bounce-spanning persistent launch (pt_kernels.hip, k_persist): state set-up (k_persist_init) + the launch, `waves` wavefronts;

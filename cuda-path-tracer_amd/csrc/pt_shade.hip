@@ -84,6 +84,55 @@ __global__ __launch_bounds__(256) void k_raygen(DCameras cams, DBatchInfo bi, DB
   if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, tile, tiles, scan);
 }
 
+// "prefold" at bounce 0: ray generation for a scene whose object list opens with a sphere run in front of a mesh (config 2).  The
+// primary ray is in registers: k_spheres<first, filter>'s work for it -- the run, the hit or miss record, the byte that says
+// whether it goes on the mesh launch's work list (shade_tile<.., kNext> does the same for the later bounces) -- is done here, and
+// bounce 0 starts with k_list_flags.
+__global__ __launch_bounds__(256) void k_raygen_next(DScene sc, DCameras cams, DBatchInfo bi, DBand band, uint32_t pix_count, DPaths paths,
+                                                     DeviceCounters* counters, DNextRun next)
+{
+  const uint32_t frame = blockIdx.x % bi.count;
+  const DCamera& cam = cams.c[frame];
+  const uint32_t iteration = bi.iteration[frame];
+  const size_t fo = (size_t)frame * bi.stride;
+  paths.o4 += fo;
+  paths.d4 += fo;
+  next.hits.tp += fo;
+  next.hits.nm += fo;
+  next.flags += fo;
+  counters += frame;
+  const uint32_t tile = blockIdx.x / bi.count;
+  const uint32_t block_first = tile * (256u * kListPer);
+  if (tile == 0u) {
+    if (threadIdx.x == 0u) counters->live[0] = pix_count;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kWorkSlots * 8u; i += 256u) (&counters->work[0][0][0])[i * 32u] = 0u;
+  }
+#pragma unroll 1
+  for (int j = 0; j < kListPer; ++j) {
+    const uint32_t s = block_first + (uint32_t)j * 256u + threadIdx.x;
+    if (s >= pix_count) continue;
+    const uint32_t pixel = band_pixel(band, s);
+    const uint32_t x = pixel % cam.width, y = pixel / cam.width;
+    Minstd rng;
+    rng.seed(path_seed(pixel, iteration));
+    const float fx = (float)x + rng.uniform();
+    const float fy = (float)y + rng.uniform();
+    Ray ray;
+    generate_ray(cam, fx, fy, ray.o, ray.d);
+    stnt(&paths.o4[s], make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(pixel)));
+    stnt(&paths.d4[s], make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f));
+    ray.tmin = 1e-4f;  // (load_ray: the sign bit of a primary ray's pixel word is clear)
+    ray.tmax = FLT_MAX;
+    Hit rec;
+    bool changed = false;
+    if (next.fold_run != 0u) sphere_fold(sc, next.begin, next.end, ray, rec, changed);
+    else sphere_segment<true>(sc, next.begin, next.end, ray, rec, changed);
+    if (changed) store_hit(next.hits, s, rec);
+    else stnt(&next.hits.tp[s], make_float4(-1.0f, 0.f, 0.f, 0.f));
+    next.flags[s] = may_hit_boxes(sc.objects, next.filt_begin, next.filt_end, ray.o, ray.d, ray.tmax) ? (uint8_t)1 : (uint8_t)0;
+  }
+}
+
 // A run of sphere objects that does not end the object list (the spheres in front of a mesh), continuing from /
 // handing on the closest hit in the hit record.  (The run that ENDS the list -- or is the whole list -- is part of
 // the kernel that ends the bounce.)  (Taking the sphere runs into the traversal kernel instead was tried in round 2: inlined or as a
@@ -154,6 +203,93 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SPHERES_
     if (kFilter && may_hit_boxes(sc.objects, filt_begin, filt_end, ray.o, ray.d, ray.tmax)) may_mask |= 1u << j;
   }
   if (kFilter) list_rays(may_mask, worklist, counters, (size_t)frame * bi.stride, tile, tiles, scan);
+}
+
+// "prefold": the work list of a bounce whose leading sphere run the shade kernel of the bounce before has walked for every
+// survivor (shade_tile<.., kNext>): k_spheres<.., kFilter>'s list -- the flagged slots in slot order, the frame's count in
+// DeviceCounters::list_count -- from the bytes that kernel left, one per slot.  A compaction of its own rather than list_rays: a
+// workgroup takes 4096 consecutive slots, every thread sixteen of them in ONE 16-byte load (the first form, list_rays' 1024-slot
+// tiles with a byte per load, spent 234 us per launch on 28,800 workgroups' chains of ticket, load, look-back and store: as
+// long as the k_traverse4m launch behind it took to walk its rays' first nodes).  Tiles by ticket and look-back over the
+// slot's descriptors as everywhere (a launch of its own epoch).
+constexpr uint32_t kFlagsPer = 16u, kFlagsTile = 256u * kFlagsPer;
+__global__ __launch_bounds__(256) void k_list_flags(const uint8_t* flags, int bounce, DeviceCounters* counters, DBatchInfo bi, uint32_t* worklist,
+                                                    DTileScan scan, uint32_t tile_stride)
+{
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_base, s_tile;
+  const uint32_t frame = blockIdx.x % bi.count;
+  const size_t fo = (size_t)frame * bi.stride;
+  flags += fo;
+  counters += frame;
+  scan.desc += (size_t)frame * tile_stride;
+  const uint32_t n = counters->live[bounce];
+  const uint32_t tiles = (n + kFlagsTile - 1u) / kFlagsTile;
+  if (blockIdx.x / bi.count >= tiles) {
+    if (tiles == 0u && blockIdx.x / bi.count == 0u && threadIdx.x == 0u) counters->list_count = 0u;  // nothing alive: an empty list
+    return;
+  }
+  if (threadIdx.x == 0u) {
+    const uint32_t t = __hip_atomic_fetch_add(&counters->shade_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1u == tiles) __hip_atomic_store(&counters->shade_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t first = tile * kFlagsTile + threadIdx.x * kFlagsPer;  // this thread's sixteen slots: first .. first + 15
+  // (the flag array is a frame's stride long and the stride a multiple of 16? not necessarily: a thread whose sixteen bytes
+  // cross the live count reads them one by one)
+  uint32_t bits = 0u;
+  if (first + kFlagsPer <= n && ((reinterpret_cast<uintptr_t>(flags + first) & 15u) == 0u)) {
+    const uint4 w = *reinterpret_cast<const uint4*>(flags + first);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bits |= ((ww[q] >> (8 * k)) & 0xffu) != 0u ? 1u << (4 * q + k) : 0u;
+  } else {
+    for (uint32_t k = 0u; k < kFlagsPer; ++k)
+      if (first + k < n && flags[first + k] != 0u) bits |= 1u << k;
+  }
+  const uint32_t mine = (uint32_t)__popc(bits);
+  // exclusive prefix within the wavefront, then across the workgroup's four
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((int)(threadIdx.x & 63u) >= off) incl += up;
+  }
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 63u) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0u, agg = 0u;
+#pragma unroll
+  for (uint32_t w = 0u; w < 4u; ++w) {
+    before += w < wave ? s_wave[w] : 0u;
+    agg += s_wave[w];
+  }
+  if (wave == 0u) {
+    const unsigned long long tag = (unsigned long long)scan.epoch << 34;
+    if (threadIdx.x == 0u)
+      __hip_atomic_store(&scan.desc[tile], tag | (tile == 0u ? kDescPrefix : kDescAggregate) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0u;
+    if (tile != 0u) {
+      excl = tile_lookback(scan.desc, tile, scan.epoch, &counters->flags);
+      if (threadIdx.x == 0u)
+        __hip_atomic_store(&scan.desc[tile], tag | kDescPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0u) {
+      s_base = excl;
+      if (tile + 1u == tiles) counters->list_count = excl + agg;
+    }
+  }
+  __syncthreads();
+  uint32_t at = s_base + before + (incl - mine);
+  while (bits != 0u) {
+    const uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
+    bits &= bits - 1u;
+    worklist[fo + at++] = (uint32_t)fo + first + k;
+  }
 }
 
 // The end of a bounce's closest-hit stage: the sphere run that ends the object list (if any) and the live count of
@@ -356,13 +492,14 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
 #include "pt_shade_tile.inc"
 
 
-template <bool kSpheres, bool kFirst>
+template <bool kSpheres, bool kFirst, bool kNext = false>
 // (occupancy bounds re-measured on the final build: at least 5 or 6 wavefronts per SIMD forces spills, -8 % / -13 % end
 // to end; 1 to 3 compile to the same 124 registers)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, 8))) void k_shade_fused(DScene sc, uint32_t obj_begin, uint32_t obj_end, DPaths in, DPaths out, DHits hits,
                                                      int staged, int bounce, int last_bounce, const uint32_t* slot_base,
                                                      unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb,
-                                                     DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi, const uint32_t* list)
+                                                     DBand band, DeviceCounters* counters, uint8_t* octs, DBatchInfo bi, const uint32_t* list,
+                                                     DNextRun next)
 {
   __shared__ uint32_t s_excl, s_tile;
   __shared__ uint32_t s_cnt[kFuseK * 4];
@@ -413,8 +550,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WA
   const uint32_t tile = s_tile;
 
   // (the tile itself: pt_shade_tile.inc, shared with the persistent launch's service wavefronts)
-  shade_tile<kSpheres, kFirst, 4, false>(sc, obj_begin, obj_end, in, out, hits, staged, bounce, last_bounce, slot_base, tile_desc, epoch, fb, band, counters,
-                                         octs, iteration, list, fo, tile, tiles, n, n_all, s_cnt, &s_excl);
+  if (kNext) {  // (the next bounce's records and bytes of this frame)
+    next.hits.tp += fo;
+    next.hits.nm += fo;
+    next.flags += fo;
+  }
+  shade_tile<kSpheres, kFirst, 4, false, kNext>(sc, obj_begin, obj_end, in, out, hits, staged, bounce, last_bounce, slot_base, tile_desc, epoch, fb, band,
+                                                counters, octs, iteration, list, fo, tile, tiles, n, n_all, s_cnt, &s_excl, &next);
 }
 
 // Ray sorting ("ray_sort", BASELINE.json's ray-sorted wavefront; the reference keeps a sort_by_key by material
@@ -534,6 +676,12 @@ void launch_raygen(hipStream_t s, const DCameras& cams, const DBatchInfo& bi, DB
                        hits, scan, tile_stride, fb, 0);
   }
 }
+void launch_raygen_next(hipStream_t s, const DScene& scene, const DCameras& cams, const DBatchInfo& bi, DBand band, uint32_t pix_count, DPaths paths,
+                        DeviceCounters* counters, const DNextRun& next)
+{
+  const dim3 grid(div_up(pix_count, 256u * kListPer) * bi.count), block(256);
+  hipLaunchKernelGGL(k_raygen_next, grid, block, 0, s, scene, cams, bi, band, pix_count, paths, counters, next);
+}
 void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths, DHits hits,
                     uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi, uint32_t filt_begin,
                     uint32_t filt_end, uint32_t* worklist, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch)
@@ -551,6 +699,13 @@ void launch_spheres(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint
     else PT_SPHERES(false, false);
   }
 #undef PT_SPHERES
+}
+void launch_list_flags(hipStream_t s, const uint8_t* flags, uint32_t max_paths, int bounce, DeviceCounters* counters, const DBatchInfo& bi,
+                       uint32_t* worklist, unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch)
+{
+  const dim3 grid(div_up(max_paths, kFlagsTile) * bi.count), block(256);
+  const DTileScan scan{tile_desc, epoch};
+  hipLaunchKernelGGL(k_list_flags, grid, block, 0, s, flags, bounce, counters, bi, worklist, scan, tile_stride);
 }
 void launch_tail_count(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths paths,
                        DHits hits, uint32_t max_paths, int bounce, uint32_t* chunk_counts, DeviceCounters* counters,
@@ -582,19 +737,23 @@ void launch_shade(hipStream_t s, const DScene& scene, DPaths in, DPaths out, DHi
 void launch_shade_fused(hipStream_t s, const DScene& scene, uint32_t obj_begin, uint32_t obj_end, bool first, DPaths in, DPaths out,
                         DHits hits, uint32_t max_paths, bool staged, int bounce, bool last_bounce, const uint32_t* slot_base,
                         unsigned long long* tile_desc, uint32_t tile_stride, uint32_t epoch, DFrame fb, DBand band,
-                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list)
+                        DeviceCounters* counters, uint8_t* octs, const DBatchInfo& bi, const uint32_t* list, const DNextRun* next)
 {
   const dim3 grid(div_up(max_paths, kFuseTile) * bi.count), block(256);
-#define PT_FUSED(SPH, FIRST)                                                                                                   \
-  hipLaunchKernelGGL((k_shade_fused<SPH, FIRST>), grid, block, 0, s, scene, obj_begin, obj_end, in, out, hits, staged ? 1 : 0, \
-                     bounce, last_bounce ? 1 : 0, slot_base, tile_desc, tile_stride, epoch, fb, band, counters, octs, bi, list)
-  if (obj_begin < obj_end) {
-    if (first) PT_FUSED(true, true);
-    else PT_FUSED(true, false);
+  const DNextRun none{};
+#define PT_FUSED(SPH, FIRST, NEXT)                                                                                                 \
+  hipLaunchKernelGGL((k_shade_fused<SPH, FIRST, NEXT>), grid, block, 0, s, scene, obj_begin, obj_end, in, out, hits, staged ? 1 : 0, \
+                     bounce, last_bounce ? 1 : 0, slot_base, tile_desc, tile_stride, epoch, fb, band, counters, octs, bi, list, next ? *next : none)
+  if (next && !first && !last_bounce) {  // "prefold": the next bounce's leading sphere run rides along
+    if (obj_begin < obj_end) PT_FUSED(true, false, true);
+    else PT_FUSED(false, false, true);
+  } else if (obj_begin < obj_end) {
+    if (first) PT_FUSED(true, true, false);
+    else PT_FUSED(true, false, false);
   } else if (first) {
-    PT_FUSED(false, true);   // a scene without objects: every ray misses
+    PT_FUSED(false, true, false);   // a scene without objects: every ray misses
   } else {
-    PT_FUSED(false, false);  // (some closest-hit launch has written every record of the bounce)
+    PT_FUSED(false, false, false);  // (some closest-hit launch has written every record of the bounce)
   }
 #undef PT_FUSED
 }

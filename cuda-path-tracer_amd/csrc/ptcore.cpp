@@ -254,8 +254,8 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   const size_t chunks = (P + kChunk - 1) / kChunk;
   int frames = std::max(1, ctx->frames_in_flight);
   if (ctx->frames_auto) {
-    // path state, hit records, staging: 164 bytes per pixel and frame in flight
-    const uint64_t per_frame = 164ull * P;
+    // path state, hit records (two sets with "prefold"), staging: 164 (197) bytes per pixel and frame in flight
+    const uint64_t per_frame = (ctx->prefold ? 197ull : 164ull) * P;
     frames = (int)std::min<uint64_t>((uint64_t)frames, std::max<uint64_t>(1ull, kAutoFrameBytes / per_frame));
   }
   const int B = std::min({std::max(1, ctx->batch_frames), frames, kMaxBatch});
@@ -291,6 +291,12 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     }
     if (int rc = dev_alloc(ctx, pool, &sl.hits.tp, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, BP)) return rc;
+    if (ctx->prefold) {
+      if (int rc = dev_alloc(ctx, pool, &sl.hits_other.tp, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.hits_other.nm, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.next_flags, BP)) return rc;
+    }
+    sl.prefolded = false;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_counts, (size_t)B * chunks)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.chunk_offsets, (size_t)B * chunks)) return rc;
     // (tile descriptors: k_shade_fused's 512-slot tiles, or the persistent launch's 128-slot ones)
@@ -495,6 +501,12 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     if (value < 2 || value > 64) return fail(ctx, PTC_ERR_INVALID, "persist_service_every must be in [2, 64]");
     if (int rc = flush_pending(ctx)) return rc;
     ctx->persist_service_every = (uint32_t)value;
+    return PTC_OK;
+  }
+  if (std::strcmp(name, "prefold") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "prefold must be 0 or 1");
+    if (ctx->pix_capacity) return fail(ctx, PTC_ERR_INVALID, "set prefold before ptc_resize");
+    ctx->prefold = value != 0;
     return PTC_OK;
   }
   if (std::strcmp(name, "pair_batches") == 0) {

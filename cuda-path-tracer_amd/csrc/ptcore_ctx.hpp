@@ -63,6 +63,10 @@ struct ptc_ctx {
     bool own_stream = false;
     DPaths paths[2]{};
     DHits hits{};
+    DHits hits_other{};             // "prefold": the second set of hit records (the shade kernel of bounce b writes bounce b + 1's while other
+                                    // tiles still read bounce b's); `hits` is always the set the current bounce reads
+    uint8_t* next_flags = nullptr;  // "prefold": per slot of the next bounce, does the ray go on the mesh launch's work list
+    bool prefolded = false;         // ... the previous bounce's shade kernel has walked this bounce's leading sphere run (k_list_flags follows)
     uint32_t* chunk_counts = nullptr;   // "fused_shade" 0: k_tail_count -> k_scan -> k_shade
     uint32_t* chunk_offsets = nullptr;
     unsigned long long* tile_desc = nullptr;  // k_shade_fused: look-back descriptors, tile_stride per frame of the batch
@@ -202,6 +206,7 @@ struct ptc_ctx {
   uint32_t est_live[2 * (kMaxBounces + 1)] = {};  // live[], then listed_now[] (DeviceCounters) of a recent batch's first frame
   bool est_valid = false;
   bool filter_rays = true;    // "filter_rays": a sphere run in front of a mesh launch also lists the rays that launch has to walk
+  bool prefold = true;        // "prefold": the kernel that ends a bounce also walks the NEXT bounce's leading sphere run for its survivors (config 2's shape)
   bool fused_shade = true;    // "fused_shade": the end of a bounce in one pass (k_shade_fused); 0: k_tail_count -> k_scan -> k_shade
   int ray_sort = 0;           // "ray_sort": 1 = traversal lanes pick their rays up grouped by direction octant (bounces >= 1)
   int denoise_variant = 0;    // "denoise_variant": 0 = taps staged in LDS (default), 1 = taps through L1 / L2

@@ -58,6 +58,26 @@ size_t launch_run(const ptc_ctx* ctx, size_t k)
   return run;
 }
 
+// may the sphere run [begin, end) take the per-lane path (sphere_run_lanes)?
+static uint32_t lanes_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
+{
+  if (!ctx->sphere_lanes || end <= begin || end - begin > 8u || end > ctx->sphere_class.size()) return 0u;
+  const uint32_t k = ctx->sphere_class[begin];
+  if (k == 0u) return 0u;
+  for (uint32_t i = begin; i < end; ++i)
+    if (ctx->sphere_class[i] != k) return 0u;
+  return 1u;
+}
+
+// may k_spheres take sphere_fold for the run [begin, end)?  Every object a "simple" sphere (sphere_ball_of)
+static uint32_t fold_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
+{
+  if (!ctx->sphere_fold || end <= begin || end > ctx->sphere_class.size()) return 0u;
+  for (uint32_t i = begin; i < end; ++i)
+    if (ctx->sphere_class[i] == 0u) return 0u;
+  return 1u;
+}
+
 int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
 {
   const int single_slots = (int)ctx->slots.size() - ctx->big_slots;
@@ -82,6 +102,7 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   sl.cur = 0;
   sl.work_slot = 0;
   sl.bounces_done = 0;
+  sl.prefolded = false;
   sl.bi.count = (uint32_t)count;
   DCameras cams{};
   for (int k = 0; k < count; ++k) {
@@ -102,6 +123,23 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   sl.primary_finished = sl.first_listed && ctx->fused_shade && launch_run(ctx, 0) == ctx->launches.size() &&
                         (!tail || ctx->tail_begin == filt_end);
   if (sl.primary_finished && tail) filt_end = ctx->tail_end;
+  // "prefold": the object list opens with a sphere run in front of a mesh launch that lists its rays -- ray generation walks
+  // the run for the primary rays itself, and bounce 0 starts with k_list_flags (batch_bounce) instead of k_spheres
+  const bool raygen_folds = ctx->prefold && ctx->trace_variant == 3 && ctx->fused_shade && ctx->filter_rays && !ctx->ray_sort && sl.next_flags &&
+                            !ctx->launches.empty() && ctx->launches[0].pre_begin < ctx->launches[0].pre_end;
+  if (raygen_folds) {
+    const auto& l0 = ctx->launches[0];
+    DNextRun next{};
+    next.begin = l0.pre_begin;
+    next.end = l0.pre_end;
+    next.filt_begin = l0.mesh;
+    next.filt_end = l0.mesh + (uint32_t)launch_run(ctx, 0);
+    next.fold_run = fold_run_of(ctx, l0.pre_begin, l0.pre_end);
+    next.hits = sl.hits;
+    next.flags = sl.next_flags;
+    launch_raygen_next(sl.stream, ctx->scene, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters, next);
+    sl.prefolded = true;
+  } else
   launch_raygen(sl.stream, cams, sl.bi, ctx->band, ctx->pix_count, sl.paths[0], sl.counters, ctx->scene.objects, first_mesh, filt_end,
                 sl.first_listed ? sl.worklist : nullptr, sl.hits, sl.tile_desc, sl.tile_stride, next_epoch(sl), sl.primary_finished,
                 sl.stage, ctx->staging());
@@ -143,26 +181,6 @@ int batch_begin(ptc_ctx* ctx, const ptc_ctx::Pending* items, int count)
   return PTC_OK;
 }
 
-// may the sphere run [begin, end) take the per-lane path (sphere_run_lanes)?
-static uint32_t lanes_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
-{
-  if (!ctx->sphere_lanes || end <= begin || end - begin > 8u || end > ctx->sphere_class.size()) return 0u;
-  const uint32_t k = ctx->sphere_class[begin];
-  if (k == 0u) return 0u;
-  for (uint32_t i = begin; i < end; ++i)
-    if (ctx->sphere_class[i] != k) return 0u;
-  return 1u;
-}
-
-// may k_spheres take sphere_fold for the run [begin, end)?  Every object a "simple" sphere (sphere_ball_of)
-static uint32_t fold_run_of(const ptc_ctx* ctx, uint32_t begin, uint32_t end)
-{
-  if (!ctx->sphere_fold || end <= begin || end > ctx->sphere_class.size()) return 0u;
-  for (uint32_t i = begin; i < end; ++i)
-    if (ctx->sphere_class[i] == 0u) return 0u;
-  return 1u;
-}
-
 int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
 {
   auto& sl = ctx->slots[(size_t)ctx->active_slot];
@@ -192,6 +210,8 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     return PTC_OK;
   };
   bool wrote = false;  // some launch of this bounce has written the hit records
+  const bool prefolded = sl.prefolded;  // ... the previous bounce's shade kernel has, for the leading sphere run ("prefold")
+  sl.prefolded = false;
   // ray sorting: the shade kernel of the previous bounce has tagged its surviving rays with their direction octant
   const bool persistent = ctx->trace_variant == 3;
   const bool sorted = ctx->ray_sort && ctx->trace_variant == 3 && bounce >= 1 && sl.order && !ctx->launches.empty();
@@ -205,7 +225,12 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       // objects at all ("filter_rays"), and the launch fetches through that list
       const bool by_spheres = ctx->filter_rays && l.pre_begin < l.pre_end && !sorted && ctx->trace_variant == 3;
       const bool listed = by_spheres || (bounce == 0 && k == 0 && sl.first_listed);  // (bounce 0's first launch: listed by k_raygen)
-      if (l.pre_begin < l.pre_end) {
+      if (l.pre_begin < l.pre_end && k == 0 && prefolded) {
+        // "prefold": the shade kernel of the bounce before has walked this run for every survivor and left the hit records
+        // (in what is now sl.hits) and one byte per ray; all that is left of k_spheres is its work list
+        launch_list_flags(sl.stream, sl.next_flags, ctx->pix_count, bounce, sl.counters, sl.bi, sl.worklist, sl.tile_desc, sl.tile_stride, next_epoch(sl));
+        wrote = true;
+      } else if (l.pre_begin < l.pre_end) {
         scene.lanes_run = lanes_run_of(ctx, l.pre_begin, l.pre_end);
         scene.fold_run = fold_run_of(ctx, l.pre_begin, l.pre_end);
         launch_spheres(sl.stream, scene, l.pre_begin, l.pre_end, !wrote, in, sl.hits, ctx->pix_count, bounce, sl.counters, sl.bi,
@@ -252,9 +277,28 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
     next_epoch(sl);
     scene.lanes_run = tail ? lanes_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
     scene.fold_run = tail && !scene.lanes_run ? fold_run_of(ctx, ctx->tail_begin, ctx->tail_end) : 0u;
+    // "prefold": the next bounce opens with a sphere run in front of its first traversal launch, which lists its rays -- this
+    // kernel walks that run for every survivor (DNextRun).  By k_spheres' own conditions: the listing is on, no ray sorting.
+    DNextRun next{};
+    const bool prefold = ctx->prefold && persistent && !last && wrote && ctx->filter_rays && !ctx->ray_sort && sl.next_flags && !ctx->launches.empty() &&
+                         ctx->launches[0].pre_begin < ctx->launches[0].pre_end;
+    if (prefold) {
+      const auto& l0 = ctx->launches[0];
+      next.begin = l0.pre_begin;
+      next.end = l0.pre_end;
+      next.filt_begin = l0.mesh;
+      next.filt_end = l0.mesh + (uint32_t)launch_run(ctx, 0);
+      next.fold_run = fold_run_of(ctx, l0.pre_begin, l0.pre_end);
+      next.hits = sl.hits_other;
+      next.flags = sl.next_flags;
+    }
     launch_shade_fused(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, out, sl.hits, ctx->pix_count,
                        ctx->staging(), bounce, last, slot_base_dev, sl.tile_desc, sl.tile_stride, sl.shade_epoch, sl.stage, ctx->band,
-                       sl.counters, octs, sl.bi, bounce == 0 && sl.primary_finished ? sl.worklist : nullptr);
+                       sl.counters, octs, sl.bi, bounce == 0 && sl.primary_finished ? sl.worklist : nullptr, prefold ? &next : nullptr);
+    if (prefold) {
+      std::swap(sl.hits, sl.hits_other);
+      sl.prefolded = true;
+    }
   } else {
     launch_tail_count(sl.stream, scene, tail ? ctx->tail_begin : 0u, tail ? ctx->tail_end : 0u, !wrote, in, sl.hits, ctx->pix_count,
                       bounce, sl.chunk_counts, sl.counters, sl.bi);
