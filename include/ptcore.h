@@ -297,6 +297,11 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *                      without rays shades "persist_help_tiles" (8) tiles before it looks again).  Bit-identical (tests/test_gpu_persist.py),
  *                      measured 0.58 x the per-bounce launches: off.  Its waits are bounded: a launch that gives up
  *                      makes ptc_get_stats fail with PTC_ERR_HIP instead of hanging.  Any time (queued frames are flushed first)
+ *   "prefold"          SCHEDULE (round 5; default 1): when a bounce opens with a sphere run in front of a mesh launch that lists its rays (a
+ *                      room's walls), the kernel that ends the bounce BEFORE walks that run for its survivors -- and ray generation for
+ *                      the primary rays -- into a second set of hit records, and the bounce starts with the work list (k_list_flags)
+ *                      instead of k_spheres.  Bit-identical; config 2 +8-9 %.  0: every bounce runs k_spheres.  Before ptc_resize
+ *                      (33 more bytes per pixel and frame in flight)
  *   "pair_batches"     SCHEDULE (round 5; default 0): 1 = a full batch is held until the next one is full (or anything else looks at
  *                      the context); the two are enqueued bounce by bounce on two slots and their traversal launches take turns.
  *                      Bit-identical, measured 6-7 % slower than the default (profiles/r05_pair_batches.txt): off.  Any time
