@@ -181,14 +181,15 @@ struct DCamera {
   uint32_t width, height;
 };
 
-// Live-path state, one float4 per path and array (48 B/path):
+// Live-path state, 40 B/path in three arrays (round 5; 48 until then: a float4 of its own for the throughput, two words unused --
+// the kernels that end a bounce are HBM-bound and read and write every word of it):
 //   o4 = origin.xyz, bits(pixel | tmin_flag<<31)   tmin_flag: t_min is 1e-5 (after a dielectric) instead of 1e-4
-//   d4 = direction.xyz, unused
-//   t4 = throughput.rgb, unused
+//   d4 = direction.xyz, throughput.r               (the closest-hit kernels load o4 and d4 and ignore d4.w; k_raygen leaves it 0:
+//   t2 = throughput.gb                              bounce 0 starts from throughput 1 without reading either)
 struct DPaths {
   float4* o4;
   float4* d4;
-  float4* t4;
+  float2* t2;
 };
 
 // Closest-hit record written by the trace kernel (32 B/path):

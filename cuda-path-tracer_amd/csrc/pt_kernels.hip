@@ -1371,10 +1371,10 @@ __device__ __forceinline__ int persist_service(const DScene& sc, const uint32_t 
       DPaths in = pa.paths[bounce & 1u], out = pa.paths[(bounce & 1u) ^ 1u];
       in.o4 += fo;
       in.d4 += fo;
-      in.t4 += fo;
+      in.t2 += fo;
       out.o4 += fo;
       out.d4 += fo;
-      out.t4 += fo;
+      out.t2 += fo;
       DHits h = hits;
       h.tp += fo;
       h.nm += fo;

@@ -395,10 +395,10 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   if (octs) octs += (size_t)frame * bi.stride;
   in.o4 += (size_t)frame * bi.stride;
   in.d4 += (size_t)frame * bi.stride;
-  in.t4 += (size_t)frame * bi.stride;
+  in.t2 += (size_t)frame * bi.stride;
   out.o4 += (size_t)frame * bi.stride;
   out.d4 += (size_t)frame * bi.stride;
-  out.t4 += (size_t)frame * bi.stride;
+  out.t2 += (size_t)frame * bi.stride;
   hits.tp += (size_t)frame * bi.stride;
   hits.nm += (size_t)frame * bi.stride;
   chunk_offsets += (size_t)frame * bi.chunk_stride;
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   if (active) {
     const float4 o4 = ldnt(&in.o4[s]);
     const float4 d4 = ldnt(&in.d4[s]);
-    const float4 t4 = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ldnt(&in.t4[s]);  // (k_raygen does not write it)
+    const float2 t2 = bounce == 0 ? make_float2(1.0f, 1.0f) : ldnt(&in.t2[s]);  // (throughput: d4.w, t2 -- DPaths; k_raygen writes neither)
     const float4 tp = ldnt(&hits.tp[s]);
     ro = xyz(o4);
     rd = xyz(d4);
-    color = xyz(t4);
+    color = mk3(bounce == 0 ? 1.0f : d4.w, t2.x, t2.y);
     pixbits = __float_as_uint(o4.w);
     const uint32_t pixel = pixbits & 0x7fffffffu;
     const uint32_t local_pixel = band_local(band, pixel);
@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths in, DPaths out,
   if (survives) {
     const uint32_t dst = chunk_offsets[s / kChunk] + rank_below(live);
     stnt(&out.o4[dst], make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixbits)));
-    stnt(&out.d4[dst], make_float4(rd.x, rd.y, rd.z, 0.0f));
-    stnt(&out.t4[dst], make_float4(color.x, color.y, color.z, 0.0f));
+    stnt(&out.d4[dst], make_float4(rd.x, rd.y, rd.z, color.x));
+    stnt(&out.t2[dst], make_float2(color.y, color.z));
     // direction octant of the new ray, for the coherence sort of the next bounce (k_sort_octant)
     if (octs) octs[dst] = (uint8_t)((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u));
   }
@@ -509,10 +509,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WA
   if (octs) octs += fo;
   in.o4 += fo;
   in.d4 += fo;
-  in.t4 += fo;
+  in.t2 += fo;
   out.o4 += fo;
   out.d4 += fo;
-  out.t4 += fo;
+  out.t2 += fo;
   hits.tp += fo;
   hits.nm += fo;
   tile_desc += (size_t)frame * tile_stride;

@@ -254,8 +254,8 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
   const size_t chunks = (P + kChunk - 1) / kChunk;
   int frames = std::max(1, ctx->frames_in_flight);
   if (ctx->frames_auto) {
-    // path state, hit records (two sets with "prefold"), staging: 164 (197) bytes per pixel and frame in flight
-    const uint64_t per_frame = (ctx->prefold ? 197ull : 164ull) * P;
+    // path state, hit records (two sets with "prefold"), staging: 148 (181) bytes per pixel and frame in flight
+    const uint64_t per_frame = (ctx->prefold ? 181ull : 148ull) * P;
     frames = (int)std::min<uint64_t>((uint64_t)frames, std::max<uint64_t>(1ull, kAutoFrameBytes / per_frame));
   }
   const int B = std::min({std::max(1, ctx->batch_frames), frames, kMaxBatch});
@@ -287,7 +287,7 @@ int ptc_resize(ptc_ctx* ctx, uint32_t width, uint32_t height)
     for (int k = 0; k < 2; ++k) {
       if (int rc = dev_alloc(ctx, pool, &sl.paths[k].o4, BP)) return rc;
       if (int rc = dev_alloc(ctx, pool, &sl.paths[k].d4, BP)) return rc;
-      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].t4, BP)) return rc;
+      if (int rc = dev_alloc(ctx, pool, &sl.paths[k].t2, BP)) return rc;
     }
     if (int rc = dev_alloc(ctx, pool, &sl.hits.tp, BP)) return rc;
     if (int rc = dev_alloc(ctx, pool, &sl.hits.nm, BP)) return rc;
