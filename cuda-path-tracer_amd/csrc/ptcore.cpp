@@ -480,6 +480,11 @@ int ptc_set_param(ptc_ctx* ctx, const char* name, int value)
     ctx->small_rays_per_lane = (uint32_t)value;
     return PTC_OK;
   }
+  if (std::strcmp(name, "run_waves") == 0) {
+    if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "run_waves out of range");
+    ctx->run_waves = (uint32_t)value;
+    return PTC_OK;
+  }
   if (std::strcmp(name, "min_waves") == 0) {
     if (value < 8 || value > 65536) return fail(ctx, PTC_ERR_INVALID, "min_waves out of range");
     ctx->min_waves = (uint32_t)value;

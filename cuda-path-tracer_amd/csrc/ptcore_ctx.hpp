@@ -201,6 +201,9 @@ struct ptc_ctx {
   uint32_t small_waves = 3072;        // "small_waves": ... of a launch with fewer than small_rays_per_lane rays per lane of a full one
   uint32_t small_rays_per_lane = 4;   // "small_rays_per_lane" (8 until round 3: bounces 5 and 6 of a 20-frame batch -- 5 to 8 rays
                                       // per lane -- are 12-14 % faster on all 5120 wavefronts than on 3072)
+  uint32_t run_waves = 3072;          // "run_waves" (round 5): most persistent wavefronts of a launch that walks a run of instances (k_traverse4m).
+                                      // Config 2 -- 4.5 M listed rays per launch, two batches in flight -- 14.0 -> 14.8 Grays/s on 1536 ... 3584
+                                      // wavefronts against 5120: the other batch's HBM-bound kernels get on the chip (profiles/r05_run_waves.txt)
   // live paths entering each bounce of one recent frame (what a frame of this scene / camera looks like): the host
   // never waits for them, they only size the traversal launches
   uint32_t est_live[2 * (kMaxBounces + 1)] = {};  // live[], then listed_now[] (DeviceCounters) of a recent batch's first frame

@@ -20,7 +20,7 @@ uint32_t next_epoch(ptc_ctx::FrameSlot& sl)
 // resident at five per SIMD).  Measured on single 1080p frames (2 M rays at the first bounce, 65 k at the eighth): one size
 // for all bounces 2.60 ms per frame, sized per bounce 2.1 ms.  The ray count of a bounce lives on the device; the
 // host sizes with the counts of a recent frame (FrameSlot::live_host), a bounce it knows nothing about with its cap.
-uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce, bool listed)
+uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce, bool listed, bool run = false)
 {
   for (auto& sl : ctx->slots)
     if (sl.live_pending && sl.done && hipEventQuery(sl.done) == hipSuccess) {
@@ -37,8 +37,10 @@ uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce, bool list
     per_frame = std::min<uint64_t>(per_frame, (uint64_t)ctx->est_live[kMaxBounces + 1 + bounce] * 9u / 8u + 64u);
   const uint64_t rays = per_frame * frames;
   // (fewer than four rays per lane at full size: 3072 wavefronts do as well or a little better -- single frames)
-  const uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * ctx->small_rays_per_lane ? ctx->traverse_waves
-                                                                                                 : std::min<uint32_t>(ctx->traverse_waves, ctx->small_waves);
+  uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * ctx->small_rays_per_lane ? ctx->traverse_waves
+                                                                                           : std::min<uint32_t>(ctx->traverse_waves, ctx->small_waves);
+  // (a launch over a run of instances, k_traverse4m: "run_waves")
+  if (run) cap = std::min<uint64_t>(cap, ctx->run_waves);
   const uint64_t want = ((rays + kWave - 1u) / kWave + 7u) & ~7ull;
   return (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(std::min<uint32_t>(ctx->min_waves, ctx->traverse_waves), want));
 }
@@ -242,7 +244,7 @@ int batch_bounce(ptc_ctx* ctx, int bounce, const uint32_t* slot_base_dev)
       if (ctx->turn_mine >= 0 && ctx->turn_wait >= 0) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, ctx->turn_event[ctx->turn_wait], 0));
       ptc_ctx::TimedLaunch tl{nullptr, nullptr, bounce};
       if (int rc = timed_begin(tl)) return rc;
-      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce, listed);
+      const uint32_t waves = traverse_waves_for(ctx, sl.bi.count, bounce, listed, run > 1);
       scene.cur = ctx->mesh_views[ctx->object_mesh[l.mesh]];  // this object's mesh
       const uint32_t* pick = listed ? sl.worklist : (sorted ? sl.order : nullptr);
       if (run > 1) {
