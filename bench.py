@@ -124,9 +124,10 @@ def pmc_record(name, frames_per_launch):
     return rec
 
 
-def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, pmc_scene=True, pixels=0, frames=0):
+def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, pmc_scene=True, pixels=0, frames=0, pmc_tag=""):
     """SURVEY 8(d) pricing of the closest-hit launches of the timed region.  pmc_scene: the counter records under
-    profiles/ were taken on THIS scene (config 3); otherwise traffic / valu are null."""
+    profiles/ (pmc_traffic_<tag><frames per launch>.json, pmc_sq_...: tag "" = config 3, "c2_" = config 2) were taken on THIS
+    scene; otherwise traffic / valu are null."""
     scale = [(paths_timed[b] / counted["paths"][b]) if counted["paths"][b] else 0.0 for b in range(MB)]
     rays = sum(paths_timed)
     # "filter_rays": a bounce whose traversal launch fetched through a work list walked only the listed rays; the others'
@@ -142,9 +143,9 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
     trace_ms = sum(prof["trace_ms"])
     launches = sum(prof["trace_launches"])
     achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    traffic_rec = pmc_record("pmc_traffic_%d.json", frames_per_launch) if pmc_scene else None
+    traffic_rec = pmc_record("pmc_traffic_" + pmc_tag + "%d.json", frames_per_launch) if pmc_scene else None
     traffic = None
-    note = None if pmc_scene else "null: no counter record for this scene (profiles/pmc_*.json are config 3)"
+    note = None if pmc_scene else "null: no counter record for this scene (profiles/pmc_*.json are configs 2 and 3 at their default sizes)"
     if traffic_rec is not None:
         if traffic_rec["matches_this_run"]:
             traffic = traffic_rec.get("trace_kernel_hbm_bytes_per_launch")
@@ -195,7 +196,7 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
                                "achieved": round(frame_bytes * frames / elapsed / 1e9, 2),
                                "frac": round(frame_bytes * frames / elapsed / 1e9 / HBM_PEAK_GBS, 4),
                                "pricing": "SURVEY 8(d): sum_b n_b*168 + node_visits*32 + tri_tests*48 + P*(65+56) bytes per frame / wall time per frame"}
-    sq = pmc_record("pmc_sq_%d.json", frames_per_launch) if pmc_scene else None
+    sq = pmc_record("pmc_sq_" + pmc_tag + "%d.json", frames_per_launch) if pmc_scene else None
     if sq is not None:
         roof["valu"] = {k: sq.get(k) for k in ("valu_pipe_frac", "lanes_per_valu_inst", "valu_inst_per_ray", "vmem_inst_per_ray",
                                                 "salu_inst_per_ray", "l2_hit_frac", "wave_occupancy_frac", "frames_per_launch",
@@ -207,12 +208,22 @@ def trace_roofline(prof, counted, paths_timed, MB, elapsed, frames_per_launch, p
             roof["valu"]["l1_tag_accesses_per_cycle_per_cu"] = round(raw["TCP_TOTAL_CACHE_ACCESSES_sum"] / (us * 1e-6 * clk * 1e9 * 256), 3)
         # what the counters say binds the kernel: VALU issue at under half the lanes, and the vector L1's
         # tag rate; the fabric carries a quarter of its peak.  The SURVEY 8(d) HBM pricing stays in achieved / peak / frac.
-        roof["bound"] = "valu-issue / vL1D"
-        roof["bound_note"] = ("from counters (profiles/pmc_sq_*.json): VALU pipe %.2f at %.1f of 64 lanes, %s L1 tag accesses per cycle and CU, "
-                              "L2 hit rate %.2f; fabric traffic is a quarter of the HBM peak -- achieved / peak / frac price the kernel "
-                              "against HBM as SURVEY 8(d) prescribes (priced_against), they do not name what binds it"
-                              % (sq.get("valu_pipe_frac") or 0, sq.get("lanes_per_valu_inst") or 0,
-                                 roof["valu"].get("l1_tag_accesses_per_cycle_per_cu"), sq.get("l2_hit_frac") or 0))
+        l1 = roof["valu"].get("l1_tag_accesses_per_cycle_per_cu") or 0.0
+        if (sq.get("valu_pipe_frac") or 0) >= 0.45 or l1 >= 0.6:
+            roof["bound"] = "valu-issue / vL1D"
+            roof["bound_note"] = ("from counters (profiles/pmc_sq_*.json): VALU pipe %.2f at %.1f of 64 lanes, %s L1 tag accesses per cycle and CU, "
+                                  "L2 hit rate %.2f; fabric traffic is a quarter of the HBM peak -- achieved / peak / frac price the kernel "
+                                  "against HBM as SURVEY 8(d) prescribes (priced_against), they do not name what binds it"
+                                  % (sq.get("valu_pipe_frac") or 0, sq.get("lanes_per_valu_inst") or 0, l1, sq.get("l2_hit_frac") or 0))
+        else:
+            # (config 2's launch over the two instances: few listed rays, each with its fixed round trips)
+            roof["bound"] = "latency (dependent round trips per ray)"
+            roof["bound_note"] = ("from counters (profiles/pmc_sq_%s*.json): VALU pipe %.2f at %.1f of 64 lanes, %s L1 tag accesses per cycle and CU, L2 hit rate "
+                                  "%.2f, wavefront-slot occupancy %.2f -- no unit is busy half the time; a listed ray's fetch, root tests, winner check and "
+                                  "store are dependent round trips that %d wavefronts per SIMD do not cover.  achieved / peak / frac price the kernel "
+                                  "against HBM as SURVEY 8(d) prescribes (priced_against)"
+                                  % (pmc_tag, sq.get("valu_pipe_frac") or 0, sq.get("lanes_per_valu_inst") or 0, l1, sq.get("l2_hit_frac") or 0,
+                                     sq.get("wave_occupancy_frac") or 0, round((raw.get("SQ_WAVES") or 0) / 1024.0)))
     return roof
 
 
@@ -755,7 +766,9 @@ def run_config2(args, pkg, torch, local_rank):
         pt.path_trace(scene.camera)
     counted = pt.profile()
     pt.set_profiling(False, False)
-    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=False, pixels=W * H, frames=args.steps)
+    # (counter records of this scene: profiles/pmc_*_c2_32.json, taken on the default workload with the default parameters)
+    pmc_scene = (W, H, MB) == (1280, 720, 8) and not args.param and args.trace_variant in (-1, 3)
+    roofline = trace_roofline(prof, counted, list(prof["paths"]), MB, elapsed, batch, pmc_scene=pmc_scene, pixels=W * H, frames=args.steps, pmc_tag="c2_")
     roofline["kernel"] = roofline["kernel"].replace("k_traverse4 (", "k_traverse4m (both instances of the mesh in one launch per bounce; ")
     roofline["note"] = ("%.1f node visits per ray: the fixed round trips of a ray (fetch, root, winner's parent box and normal, store) "
                         "weigh more than its walk" % roofline["node_visits_per_ray"])
