@@ -39,8 +39,8 @@ uint32_t traverse_waves_for(ptc_ctx* ctx, uint32_t frames, int bounce, bool list
   // (fewer than four rays per lane at full size: 3072 wavefronts do as well or a little better -- single frames)
   uint64_t cap = rays >= (uint64_t)ctx->traverse_waves * kWave * ctx->small_rays_per_lane ? ctx->traverse_waves
                                                                                            : std::min<uint32_t>(ctx->traverse_waves, ctx->small_waves);
-  // (a launch over a run of instances, k_traverse4m: "run_waves")
-  if (run) cap = std::min<uint64_t>(cap, ctx->run_waves);
+  // (a launch over a run of instances, k_traverse4m: "run_waves" -- room for the other batch's kernels, so only when there is one)
+  if (run && ctx->big_slots >= 2) cap = std::min<uint64_t>(cap, ctx->run_waves);
   const uint64_t want = ((rays + kWave - 1u) / kWave + 7u) & ~7ull;
   return (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(std::min<uint32_t>(ctx->min_waves, ctx->traverse_waves), want));
 }

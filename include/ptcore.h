@@ -291,7 +291,8 @@ int ptc_set_trace_variant(ptc_ctx* ctx, int variant);
  *   "small_waves", "small_rays_per_lane"  a traversal launch with fewer than small_rays_per_lane (default 4) rays per lane of
  *                      "traverse_waves" wavefronts uses at most small_waves (default 3072) of them
  *   "run_waves"        SCHEDULE (round 5; default 3072): most wavefronts of a launch that walks a run of instances of one mesh
- *                      (k_traverse4m; config 2: +5 % against 5120 with two batches in flight)
+ *                      (k_traverse4m) when the context has two or more batch slots: the other batch's HBM-bound kernels get on the
+ *                      chip beside it (config 2: +6 % against 5120)
  *   "persist"          SCHEDULE (round 5; default 0): 1 = a batch of at least "persist_min_frames" (2) frames whose launch plan is one
  *                      mesh object per bounce with nothing in front of it (fused shade, staged samples, no ray sorting, not instrumented)
  *                      runs bounce 0's traversal as ever and then ONE launch for the traversal of bounces >= 1 and every shade pass
